@@ -1,0 +1,135 @@
+"""ctypes mirror of include/lajolla_hip.h (kept field-for-field in the header's order)."""
+import ctypes as C
+
+LJ_OK = 0
+LJ_ERR_INVALID_ARG, LJ_ERR_PARSE, LJ_ERR_IO, LJ_ERR_UNSUPPORTED, LJ_ERR_DEVICE, LJ_ERR_INTERNAL = -1, -2, -3, -4, -5, -6
+
+LJ_FILTER_BOX, LJ_FILTER_TENT, LJ_FILTER_GAUSSIAN = 0, 1, 2
+LJ_SHAPE_SPHERE, LJ_SHAPE_TRIMESH = 0, 1
+LJ_TEX_CONSTANT, LJ_TEX_IMAGE, LJ_TEX_CHECKERBOARD = 0, 1, 2
+LJ_LIGHT_AREA, LJ_LIGHT_ENVMAP = 0, 1
+MATERIAL_KINDS = ["lambertian", "roughplastic", "roughdielectric", "disneydiffuse", "disneymetal",
+                  "disneyglass", "disneyclearcoat", "disneysheen", "disneybsdf"]
+LJ_INTEGRATOR_PATH = 5
+LJ_MAX_TEX_SLOTS = 12
+INT32_MIN = -2**31
+
+# texture slot names per material kind, in the reference's field order (material.h:12-98)
+MATERIAL_SLOTS = {
+    "lambertian": ["reflectance"],
+    "roughplastic": ["diffuse_reflectance", "specular_reflectance", "roughness"],
+    "roughdielectric": ["specular_reflectance", "specular_transmittance", "roughness"],
+    "disneydiffuse": ["base_color", "roughness", "subsurface"],
+    "disneymetal": ["base_color", "roughness", "anisotropic"],
+    "disneyglass": ["base_color", "roughness", "anisotropic"],
+    "disneyclearcoat": ["clearcoat_gloss"],
+    "disneysheen": ["base_color", "sheen_tint"],
+    "disneybsdf": ["base_color", "specular_transmission", "metallic", "subsurface", "specular", "roughness",
+                   "specular_tint", "anisotropic", "sheen", "sheen_tint", "clearcoat", "clearcoat_gloss"],
+}
+# which slots are Texture<Spectrum> (others are Texture<Real>)
+SPECTRUM_SLOTS = {"reflectance", "diffuse_reflectance", "specular_reflectance", "specular_transmittance", "base_color"}
+
+
+class LjTexture(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("texture_id", C.c_int32), ("value", C.c_double * 3), ("color1", C.c_double * 3),
+                ("uscale", C.c_double), ("vscale", C.c_double), ("uoffset", C.c_double), ("voffset", C.c_double)]
+
+
+class LjMaterial(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("n_tex", C.c_int32), ("eta", C.c_double), ("tex", LjTexture * LJ_MAX_TEX_SLOTS)]
+
+
+class LjShape(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("material_id", C.c_int32), ("area_light_id", C.c_int32),
+                ("interior_medium_id", C.c_int32), ("exterior_medium_id", C.c_int32),
+                ("has_normals", C.c_int32), ("has_uvs", C.c_int32), ("_pad", C.c_int32),
+                ("first_vertex", C.c_int64), ("n_vertices", C.c_int64),
+                ("first_triangle", C.c_int64), ("n_triangles", C.c_int64),
+                ("position", C.c_double * 3), ("radius", C.c_double)]
+
+
+class LjLight(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("shape_id", C.c_int32), ("intensity", C.c_double * 3), ("values", LjTexture),
+                ("to_world", C.c_double * 16), ("to_local", C.c_double * 16), ("scale", C.c_double)]
+
+
+class LjImage(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("channels", C.c_int32), ("_pad", C.c_int32),
+                ("data", C.POINTER(C.c_float))]
+
+
+class LjCamera(C.Structure):
+    _fields_ = [("cam_to_world", C.c_double * 16), ("world_to_cam", C.c_double * 16),
+                ("sample_to_cam", C.c_double * 16), ("cam_to_sample", C.c_double * 16),
+                ("width", C.c_int32), ("height", C.c_int32), ("filter_kind", C.c_int32), ("medium_id", C.c_int32),
+                ("filter_param", C.c_double)]
+
+
+class LjRenderOptions(C.Structure):
+    _fields_ = [("integrator", C.c_int32), ("samples_per_pixel", C.c_int32), ("max_depth", C.c_int32),
+                ("rr_depth", C.c_int32), ("vol_path_version", C.c_int32), ("max_null_collisions", C.c_int32)]
+
+
+class LjSceneDesc(C.Structure):
+    _fields_ = [("camera", LjCamera), ("options", LjRenderOptions),
+                ("n_shapes", C.c_int32), ("n_materials", C.c_int32), ("n_lights", C.c_int32),
+                ("n_images3", C.c_int32), ("n_images1", C.c_int32), ("envmap_light_id", C.c_int32),
+                ("shapes", C.POINTER(LjShape)), ("materials", C.POINTER(LjMaterial)), ("lights", C.POINTER(LjLight)),
+                ("images3", C.POINTER(LjImage)), ("images1", C.POINTER(LjImage)),
+                ("n_vertices", C.c_int64), ("n_triangles", C.c_int64),
+                ("positions", C.POINTER(C.c_double)), ("normals", C.POINTER(C.c_double)),
+                ("uvs", C.POINTER(C.c_double)), ("indices", C.POINTER(C.c_int32)),
+                ("output_filename", C.c_char_p)]
+
+
+class LjRenderArgs(C.Structure):
+    _fields_ = [("spp", C.c_int32), ("max_depth", C.c_int32), ("rng_mode", C.c_int32),
+                ("rank", C.c_int32), ("world_size", C.c_int32),
+                ("crop_x0", C.c_int32), ("crop_y0", C.c_int32), ("crop_x1", C.c_int32), ("crop_y1", C.c_int32),
+                ("pool_paths", C.c_uint32), ("flags", C.c_uint32), ("seed", C.c_uint64)]
+
+
+class LjRay(C.Structure):
+    _fields_ = [("org", C.c_float * 3), ("tnear", C.c_float), ("dir", C.c_float * 3), ("tfar", C.c_float)]
+
+
+class LjHit(C.Structure):
+    _fields_ = [("t", C.c_float), ("u", C.c_float), ("v", C.c_float), ("shape_id", C.c_int32), ("prim_id", C.c_int32)]
+
+
+class LjStats(C.Structure):
+    _fields_ = [("samples", C.c_uint64), ("bounce_iterations", C.c_uint64), ("rays_closest", C.c_uint64),
+                ("rays_shadow", C.c_uint64), ("wavefront_steps", C.c_uint64), ("queue_bytes", C.c_uint64),
+                ("render_ms", C.c_double), ("extend_ms", C.c_double), ("shade_ms", C.c_double),
+                ("generate_ms", C.c_double), ("resolve_ms", C.c_double),
+                ("extend_launches", C.c_uint64), ("shade_launches", C.c_uint64),
+                ("extend_bytes", C.c_uint64), ("shade_bytes", C.c_uint64)]
+
+
+class LjSceneInfo(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("spp", C.c_int32), ("max_depth", C.c_int32),
+                ("rr_depth", C.c_int32), ("integrator", C.c_int32),
+                ("n_triangles", C.c_int64), ("n_spheres", C.c_int64), ("n_bvh_nodes", C.c_int64),
+                ("bounds_radius", C.c_double), ("bounds_center", C.c_double * 3), ("shadow_epsilon", C.c_double)]
+
+
+# every symbol include/lajolla_hip.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("lj_last_error", C.c_char_p, []),
+    ("lj_version", C.c_char_p, []),
+    ("lj_parse_scene", C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    ("lj_host_scene_desc", C.POINTER(LjSceneDesc), [C.c_void_p]),
+    ("lj_host_scene_free", None, [C.c_void_p]),
+    ("lj_context_create", C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    ("lj_context_destroy", None, [C.c_void_p]),
+    ("lj_scene_upload", C.c_int, [C.c_void_p, C.POINTER(LjSceneDesc), C.POINTER(C.c_void_p)]),
+    ("lj_scene_destroy", None, [C.c_void_p]),
+    ("lj_render", C.c_int, [C.c_void_p, C.POINTER(LjRenderArgs), C.c_void_p]),
+    ("lj_render_device", C.c_int, [C.c_void_p, C.POINTER(LjRenderArgs), C.c_void_p, C.c_void_p]),
+    ("lj_render_samples", C.c_int, [C.c_void_p, C.POINTER(LjRenderArgs), C.c_void_p]),
+    ("lj_intersect", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    ("lj_occluded", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    ("lj_get_stats", C.c_int, [C.c_void_p, C.POINTER(LjStats)]),
+    ("lj_scene_info", C.c_int, [C.c_void_p, C.POINTER(LjSceneInfo)]),
+]

@@ -1,0 +1,121 @@
+"""Build liblajolla_hip.so (product) — and, for the test infrastructure, oracle/_build/liblj_oracle.so.
+
+    python -m lajolla_public_amd.build            # product library (hipcc --offload-arch=gfx950, cross-compiles without a GPU)
+    python -m lajolla_public_amd.build --oracle   # also the CPU oracle (g++), test infrastructure only
+    python -m lajolla_public_amd.build --twin     # also the host build of the device headers used by CPU-side tests
+
+Objects are cached under build/ and rebuilt when a source or header is newer.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "lajolla_public_amd", "csrc")
+BUILD = os.path.join(ROOT, "build")
+LIB = os.path.join(ROOT, "lajolla_public_amd", "liblajolla_hip.so")
+ORACLE_LIB = os.path.join(ROOT, "oracle", "_build", "liblj_oracle.so")
+TWIN_LIB = os.path.join(ROOT, "tests", "twin", "_build", "libljtwin.so")
+
+HOST_SOURCES = ["host/api_host.cpp", "host/scene_xml.cpp", "host/mesh_io.cpp", "host/image_io.cpp", "host/flatten.cpp", "host/bvh.cpp"]
+HIP_SOURCES = ["device/kernels.hip", "device/api_device.hip"]
+ARCH = "gfx950"
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _headers():
+    out = [os.path.join(ROOT, "include", "lajolla_hip.h")]
+    for d, _, files in os.walk(CSRC):
+        out += [os.path.join(d, f) for f in files if f.endswith(".h")]
+    return out
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("command failed: " + " ".join(cmd) + "\n" + r.stdout)
+    if r.stdout.strip():
+        sys.stderr.write(r.stdout)
+
+
+def build_product(verbose=True):
+    os.makedirs(BUILD, exist_ok=True)
+    headers = _headers()
+    jobs = []
+    objs = []
+    for src in HOST_SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(BUILD, src.replace("/", "_") + ".o")
+        objs.append(o)
+        if _stale(o, [s] + headers):
+            jobs.append(["g++", "-std=c++17", "-O2", "-fPIC", "-Wall", "-Wno-unused-function", "-c", s, "-o", o])
+    for src in HIP_SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(BUILD, src.replace("/", "_") + ".o")
+        objs.append(o)
+        if _stale(o, [s] + headers):
+            jobs.append([_hipcc(), "-std=c++17", "-O3", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+                         "-fno-gpu-rdc", "-c", s, "-o", o])
+    if jobs:
+        if verbose:
+            print(f"[build] compiling {len(jobs)} translation unit(s) for {ARCH}", file=sys.stderr)
+        with ThreadPoolExecutor(max_workers=4) as ex:
+            list(ex.map(_run, jobs))
+    if jobs or _stale(LIB, objs):
+        _run([_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs + ["-lz"])
+    return LIB
+
+
+def build_oracle(verbose=True):
+    src = os.path.join(ROOT, "oracle", "lj_oracle.cpp")
+    os.makedirs(os.path.dirname(ORACLE_LIB), exist_ok=True)
+    if _stale(ORACLE_LIB, [src, os.path.join(ROOT, "include", "lajolla_hip.h")]):
+        if verbose:
+            print("[build] compiling the CPU oracle (test infrastructure)", file=sys.stderr)
+        _run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
+              "-o", ORACLE_LIB, src, "-lpthread"])
+    return ORACLE_LIB
+
+
+def build_twin(verbose=True):
+    src = os.path.join(ROOT, "tests", "twin", "twin.cpp")
+    if not os.path.exists(src):
+        return None
+    os.makedirs(os.path.dirname(TWIN_LIB), exist_ok=True)
+    deps = [src] + _headers() + [os.path.join(CSRC, s) for s in ("host/flatten.cpp", "host/bvh.cpp")]
+    if _stale(TWIN_LIB, deps):
+        if verbose:
+            print("[build] compiling the host twin of the device headers (CPU-side tests only)", file=sys.stderr)
+        _run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
+              "-o", TWIN_LIB, src, os.path.join(CSRC, "host/flatten.cpp"), os.path.join(CSRC, "host/bvh.cpp"), "-lpthread"])
+    return TWIN_LIB
+
+
+def build_reference_subset():
+    """oracle/_ref from the reference's own sources — only where /root/reference exists (this container)."""
+    script = os.path.join(ROOT, "oracle", "ref_build.sh")
+    if os.path.isdir(os.environ.get("LJ_REFERENCE_ROOT", "/root/reference")):
+        _run(["bash", script])
+
+
+if __name__ == "__main__":
+    build_product()
+    if "--oracle" in sys.argv or "--all" in sys.argv:
+        build_oracle()
+    if "--twin" in sys.argv or "--all" in sys.argv:
+        build_twin()
+    print(LIB)

@@ -1,0 +1,142 @@
+// BVH traversal + primitive tests: the device replacement for rtcIntersect1 / rtcOccluded1
+// (intersection.cpp:32,83) and the sphere user-geometry callbacks (sphere.inl:40-141).
+//
+// The primitive tests are the SAME arithmetic, operation for operation, as oracle/lj_oracle.cpp's tri_test /
+// sphere_test, compiled with floating-point contraction off, so a hit record (t, u, v, primitive) is bit-identical
+// between the two for the same float ray.  The closest hit is the minimum of (t, global primitive id), which makes
+// the result independent of BVH topology and traversal order.
+#pragma once
+#include "dmath.h"
+
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+
+namespace ljd {
+
+struct RayF { float ox, oy, oz, dx, dy, dz, tnear, tfar; };
+
+// Plücker-coordinate edge tests on origin-relative vertices; see oracle/lj_oracle.cpp tri_test for the rationale.
+LJ_HD bool tri_test(const RayF &r, float tfar, const float *p0, const float *p1, const float *p2, float &t_out, float &u_out, float &v_out) {
+    float ax = p0[0] - r.ox, ay = p0[1] - r.oy, az = p0[2] - r.oz;
+    float bx = p1[0] - r.ox, by = p1[1] - r.oy, bz = p1[2] - r.oz;
+    float cx = p2[0] - r.ox, cy = p2[1] - r.oy, cz = p2[2] - r.oz;
+    float e0x = cx - ax, e0y = cy - ay, e0z = cz - az;
+    float e1x = ax - bx, e1y = ay - by, e1z = az - bz;
+    float e2x = bx - cx, e2y = by - cy, e2z = bz - cz;
+    float s0x = cx + ax, s0y = cy + ay, s0z = cz + az;
+    float s1x = ax + bx, s1y = ay + by, s1z = az + bz;
+    float s2x = bx + cx, s2y = by + cy, s2z = bz + cz;
+    float U = (e0y * s0z - e0z * s0y) * r.dx + (e0z * s0x - e0x * s0z) * r.dy + (e0x * s0y - e0y * s0x) * r.dz;
+    float V = (e1y * s1z - e1z * s1y) * r.dx + (e1z * s1x - e1x * s1z) * r.dy + (e1x * s1y - e1y * s1x) * r.dz;
+    float W = (e2y * s2z - e2z * s2y) * r.dx + (e2z * s2x - e2x * s2z) * r.dy + (e2x * s2y - e2y * s2x) * r.dz;
+    float mn = fminf(fminf(U, V), W), mx = fmaxf(fmaxf(U, V), W);
+    if (!(mn >= 0.0f || mx <= 0.0f)) return false;
+    float S = (U + V) + W;
+    if (S == 0.0f) return false;
+    float nx = e1y * e0z - e1z * e0y, ny = e1z * e0x - e1x * e0z, nz = e1x * e0y - e1y * e0x;
+    float den = (nx * r.dx + ny * r.dy) + nz * r.dz;
+    if (den == 0.0f) return false;
+    float T = (nx * ax + ny * ay) + nz * az;
+    float t = T / den;
+    if (!(t > r.tnear && t <= tfar)) return false;
+    t_out = t; u_out = U / S; v_out = V / S;
+    return true;
+}
+
+// sphere.inl:15-38 + 40-84: the reference's callback arithmetic — double maths on the float ray.
+LJ_HD bool sphere_test(const RayF &r, const DSphere &s, double &t_out) {
+    double ox = r.ox, oy = r.oy, oz = r.oz, dx = r.dx, dy = r.dy, dz = r.dz;
+    double vx = ox - s.center[0], vy = oy - s.center[1], vz = oz - s.center[2];
+    double A = dx * dx + dy * dy + dz * dz;
+    double B = 2 * (dx * vx + dy * vy + dz * vz);
+    double C = (vx * vx + vy * vy + vz * vz) - s.radius * s.radius;
+    double t0, t1;
+    if (A == 0) {
+        if (B == 0) return false;
+        t0 = t1 = -C / B;
+    } else {
+        double disc = B * B - 4 * A * C;
+        if (disc < 0) return false;
+        double rd = sqrt(disc);
+        if (B >= 0) { t0 = (-B - rd) / (2 * A); t1 = 2 * C / (-B - rd); }
+        else { t0 = 2 * C / (-B + rd); t1 = (-B + rd) / (2 * A); }
+    }
+    double tn = r.tnear, tf = r.tfar;
+    double t = -1;
+    if (t0 >= tn && t0 < tf) t = t0;
+    if (t1 >= tn && t1 < tf && t < 0) t = t1;
+    if (t >= tn && t < tf) { t_out = t; return true; }
+    return false;
+}
+
+LJ_HD bool box_test(const float *lo, const float *hi, const RayF &r, float ix, float iy, float iz, float tfar, float &tentry) {
+    float ax = (lo[0] - r.ox) * ix, bx = (hi[0] - r.ox) * ix;
+    float ay = (lo[1] - r.oy) * iy, by = (hi[1] - r.oy) * iy;
+    float az = (lo[2] - r.oz) * iz, bz = (hi[2] - r.oz) * iz;
+    float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), r.tnear));
+    float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tfar));
+    tentry = t0;
+    return t0 <= t1 * 1.0000005f;
+}
+
+struct HitRec { float t, u, v; int32_t gprim; };
+
+// Mem provides: DNode node(int i); DPrim prim(int i); const DSphere& sphere(int slot);
+//               void push(int sp, int v); int pop(int sp);   (per-lane stack storage), int max_stack()
+template <bool ANY_HIT, class Mem>
+LJ_HD bool traverse(Mem &mem, const RayF &ray, HitRec &best) {
+    best.t = ray.tfar; best.u = 0.0f; best.v = 0.0f; best.gprim = -1;
+    const float ix = 1.0f / ray.dx, iy = 1.0f / ray.dy, iz = 1.0f / ray.dz;
+    int sp = 0;
+    int cur = 0;
+    for (;;) {
+        const DNode nd = mem.node(cur);
+        float te0, te1;
+        bool h0 = box_test(nd.lo0, nd.hi0, ray, ix, iy, iz, best.t, te0);
+        bool h1 = box_test(nd.lo1, nd.hi1, ray, ix, iy, iz, best.t, te1);
+#pragma unroll 1
+        for (int side = 0; side < 2; side++) {
+            const int c = side ? nd.c1 : nd.c0;
+            const bool h = side ? h1 : h0;
+            if (!h || c >= 0) continue;
+            const int first = ~c, count = side ? nd.n1 : nd.n0;
+            for (int k = 0; k < count; k++) {
+                const DPrim p = mem.prim(first + k);
+                if (p.kind == 0) {
+                    float t, u, v;
+                    if (tri_test(ray, best.t, p.v0, p.v1, p.v2, t, u, v)) {
+                        if (ANY_HIT) { best.t = t; best.gprim = p.gprim; return true; }
+                        if (t < best.t || (t == best.t && (best.gprim < 0 || p.gprim < best.gprim))) { best.t = t; best.u = u; best.v = v; best.gprim = p.gprim; }
+                    }
+                } else {
+                    double td;
+                    if (sphere_test(ray, mem.sphere(p.sphere_slot), td)) {
+                        const float tf = (float)td;
+                        if (ANY_HIT) { best.t = tf; best.gprim = p.gprim; return true; }
+                        if (tf < best.t || (tf == best.t && (best.gprim < 0 || p.gprim < best.gprim))) { best.t = tf; best.u = 0.0f; best.v = 0.0f; best.gprim = p.gprim; }
+                    }
+                }
+            }
+        }
+        const bool g0 = h0 && nd.c0 >= 0, g1 = h1 && nd.c1 >= 0;
+        if (g0 && g1) {
+            const bool near0 = te0 <= te1;
+            const int nearc = near0 ? nd.c0 : nd.c1, farc = near0 ? nd.c1 : nd.c0;
+            if (sp < mem.max_stack()) { mem.push(sp, farc); sp++; }
+            cur = nearc;
+        } else if (g0) cur = nd.c0;
+        else if (g1) cur = nd.c1;
+        else {
+            if (sp == 0) break;
+            sp--; cur = mem.pop(sp);
+        }
+    }
+    return best.gprim >= 0;
+}
+
+} // namespace ljd
+
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif

@@ -1,0 +1,154 @@
+// Device-resident scene and wavefront queue layouts (plain PODs shared by host flattening code and HIP kernels).
+// See DESIGN.md §3 for the HBM layout rationale.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define LJ_HD __host__ __device__ __forceinline__
+#else
+#define LJ_HD inline
+#endif
+
+namespace ljd {
+
+// ---- BVH2, both child boxes stored in the parent (one 64-byte record per traversal step).
+// child >= 0: inner node index.  child < 0: leaf, prims [~child, ~child + count) of the leaf-ordered prim array.
+// An empty child has lo = +inf, hi = -inf.
+struct DNode {
+    float lo0[3]; int32_t c0;
+    float hi0[3]; int32_t c1;
+    float lo1[3]; int32_t n0;
+    float hi1[3]; int32_t n1;
+};
+static_assert(sizeof(DNode) == 64, "DNode must be 64 bytes");
+
+// Leaf-ordered primitive for the intersection tests (48 bytes = three float4).
+// kind 0: triangle, float vertices exactly as the reference hands them to Embree (triangle_mesh.inl:11-14).
+// kind 1: sphere, `gprim` indexes DScene::prims and the sphere parameters are read from there (double maths).
+struct DPrim {
+    float v0[3]; int32_t gprim;
+    float v1[3]; int32_t kind;
+    float v2[3]; int32_t sphere_slot;  // kind 1: index into DScene::spheres
+};
+static_assert(sizeof(DPrim) == 48, "DPrim must be 48 bytes");
+
+// Per-primitive shading record, indexed by global primitive id (shape order, then triangle order).
+// Everything compute_shading_info (triangle_mesh.inl:65-157 / sphere.inl:235-260) derives from per-primitive
+// constants is precomputed on the host in double and narrowed once.
+struct DPrimShade {
+    float n0[3], n1[3], n2[3];  // vertex normals (triangles with normals); sphere: centre in n0, radius in n1[0]
+    float uv0[2], uv1[2], uv2[2];
+    float dpdu[3];              // dp/du of the triangle (or Frisvad tangent of Ng when the uv map is degenerate)
+    float gn[3];                // normalize(Ng), Ng = (p1-p0)x(p2-p0) on the float vertices
+    float inv_uv_size;          // max(|dpdu|, |dpdv|)
+    int32_t shape_id, prim_id;  // what intersect() reports (intersection.cpp:42-43)
+    int32_t material_id, light_id;
+    int32_t flags;              // bit0: sphere, bit1: has vertex normals
+    int32_t sphere_slot;
+};
+static_assert(sizeof(DPrimShade) == 112, "DPrimShade layout");
+
+struct DSphere { double center[3]; double radius; };
+
+struct DTexture {
+    int32_t kind, texture_id;
+    float value[3], color1[3];
+    float uscale, vscale, uoffset, voffset;
+};
+struct DMaterial {
+    int32_t kind, n_tex;
+    float eta, _pad;
+    DTexture tex[12];
+};
+
+// Emissive triangle for sample_point_on_shape (triangle_mesh.inl:24-38)
+struct DLightTri { float v0[3], e1[3], e2[3], n[3]; };
+struct DLight {
+    int32_t kind, shape_id;
+    float intensity[3];
+    int32_t is_sphere;
+    float center[3], radius;          // sphere lights
+    int32_t tri_first, tri_count;     // into light_tris / light_tri_cdf (cdf has tri_count+1 entries starting at tri_first + light index)
+    int32_t cdf_first;
+    float total_area;
+    float pmf;                        // light_pmf(scene, id)
+    // envmap
+    float to_world[9], to_local[9];   // upper-left 3x3, row-major
+    float scale;
+    int32_t env_w, env_h, env_cdf_rows, env_pdf_rows, env_cdf_marg, env_pdf_marg;  // offsets into env_tables
+    DTexture values;
+};
+
+struct DMipLevel { int32_t w, h; int64_t offset; };  // offset in floats into texels
+struct DImage { int32_t levels, channels; DMipLevel lv[8]; };
+
+struct DCamera {
+    float sample_to_cam[16];
+    float cam_to_world[16];
+    float org[3];
+    int32_t width, height, filter_kind;
+    float filter_param;
+};
+
+struct DScene {
+    DCamera cam;
+    const DNode *nodes; int32_t n_nodes;
+    const DPrim *leaf_prims; int32_t n_prims;
+    const DPrimShade *prims;
+    const DSphere *spheres;          // indexed by sphere_slot
+    const DMaterial *materials; int32_t n_materials;
+    const DLight *lights; int32_t n_lights;
+    const float *light_cdf;          // n_lights + 1
+    const DLightTri *light_tris;
+    const float *light_tri_cdf;
+    const DImage *images3, *images1;
+    const float *texels;
+    const float *env_tables;
+    int32_t envmap_light_id;
+    int32_t max_depth, rr_depth;
+    float eps;                       // get_shadow_epsilon == get_intersection_epsilon (scene.h:99-105)
+    float init_spread;               // 0.25 / max(w, h)  (ray.h:35-37)
+};
+
+// ---- wavefront path queue: structure of arrays, one slot per in-flight path
+struct DQueue {
+    float *ox, *oy, *oz;        // ray origin = position of the vertex the path left (12 B)
+    float *dx, *dy, *dz;        // ray direction (12 B)
+    float *ht, *hu, *hv;        // hit of the extension ray: t, barycentrics (12 B)
+    int32_t *hprim;             // global primitive id, -1 = miss; bit 30 set = pending shadow ray is unoccluded (4 B)
+    float *sx, *sy, *sz, *st;   // pending NEE shadow ray: direction, tfar (<= 0: none) (16 B)
+    float *wr, *wg, *wb;        // W = throughput * f / p2(solid angle) of the sampled direction (12 B)
+    float *rr;                  // Russian-roulette survival probability applied when the path continues (4 B)
+    float *p2;                  // solid-angle pdf of the sampled direction; < 0 on camera rays (no MIS) (4 B)
+    float *lr, *lg, *lb;        // accumulated radiance (12 B)
+    float *nr, *ng, *nb;        // pending NEE contribution throughput*C1*w1, added when the shadow ray is clear (12 B)
+    uint32_t *sample;           // sample id inside this pass (4 B)
+    uint64_t *rng;              // pcg32 state; inc is derived from the stream id (8 B)
+    float *eta_scale, *spread;  // eta_scale (path_tracing.h:53), ray_diff.spread (8 B)
+    uint32_t *flags;            // bits 0-15 num_vertices of the iteration that sampled the ray; bit 16 dying after hit
+                                // accounting; bit 17 no extension ray (only the pending NEE remains) (4 B)
+};
+// bytes per slot: 124
+
+enum : uint32_t { PF_DYING = 1u << 16, PF_NO_EXT = 1u << 17 };
+enum : int32_t { HIT_VIS_BIT = 1 << 30 };
+
+struct DCtrl {
+    uint32_t n_in;        // paths in the current queue
+    uint32_t n_out;       // survivors appended to the next queue by the shade kernel
+    uint32_t n_new;       // camera samples the generate kernel appends this step
+    uint32_t gen_offset;  // first free slot for them
+    uint64_t next_sample, total_samples, gen_base;
+    uint32_t capacity, steps;
+    // counters (LjStats)
+    unsigned long long bounce_iterations, rays_closest, rays_shadow, samples_done, path_steps;
+};
+
+struct DPass {
+    const uint32_t *pixel_list;  // linear pixel index (y*w+x) of the p-th rendered pixel
+    uint32_t n_pixels, spp;
+    uint64_t seed;
+    float *sample_rgb;           // 3 floats per sample of the pass: per-sample radiance (written once per sample)
+};
+
+} // namespace ljd

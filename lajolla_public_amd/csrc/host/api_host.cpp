@@ -1,0 +1,36 @@
+// C-ABI entry points that never touch the GPU: error reporting, version, the XML front end.
+// (Device entry points live in ../device/api_device.hip.)
+#include "host_scene.h"
+#include "api_common.h"
+#include <cstring>
+
+namespace lj {
+thread_local std::string g_last_error;
+void set_last_error(const std::string &msg) { g_last_error = msg; }
+} // namespace lj
+
+struct lj_host_scene { lj::HostScene *hs; };
+
+extern "C" {
+
+const char *lj_last_error(void) { return lj::g_last_error.c_str(); }
+const char *lj_version(void) { return "lajolla_hip 0.1 (gfx950)"; }
+
+int lj_parse_scene(const char *xml_path, lj_host_scene **out) {
+    return lj::guard([&]() {
+        if (!xml_path || !out) throw lj::LjError(LJ_ERR_INVALID_ARG, "lj_parse_scene: null argument");
+        *out = nullptr;
+        lj::HostScene *hs = lj::parse_scene_xml(xml_path);
+        *out = new lj_host_scene{hs};
+    });
+}
+
+const LjSceneDesc *lj_host_scene_desc(const lj_host_scene *hs) { return hs ? &hs->hs->desc : nullptr; }
+
+void lj_host_scene_free(lj_host_scene *hs) {
+    if (!hs) return;
+    delete hs->hs;
+    delete hs;
+}
+
+} // extern "C"

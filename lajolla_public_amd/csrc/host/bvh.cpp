@@ -1,0 +1,151 @@
+// Host BVH builder: replaces Embree's rtcCommitScene (scene.cpp:20-27, build quality HIGH) with a binned-SAH
+// BVH2 whose nodes are emitted breadth-first — a prefix of the node array is the top of the tree, which is what the
+// extend kernel stages into LDS.  Each node record carries both children's boxes (one 64-byte fetch per step).
+#include "flatten.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace lj {
+
+namespace {
+
+struct Box {
+    float lo[3], hi[3];
+    Box() { for (int k = 0; k < 3; k++) { lo[k] = std::numeric_limits<float>::infinity(); hi[k] = -std::numeric_limits<float>::infinity(); } }
+    void grow(const float *l, const float *h) { for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], l[k]); hi[k] = std::max(hi[k], h[k]); } }
+    void grow(const Box &b) { grow(b.lo, b.hi); }
+    float half_area() const {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        if (!(dx >= 0 && dy >= 0 && dz >= 0)) return 0.0f;
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+struct TmpNode {
+    Box box;
+    int left = -1, right = -1;   // TmpNode indices (inner)
+    int first = 0, count = 0;    // leaf range into the order array
+    int depth = 0;
+};
+
+struct Builder {
+    const std::vector<BuildPrim> &prims;
+    std::vector<int> order;
+    std::vector<float> centroid;  // 3 per prim
+    std::vector<TmpNode> tmp;
+    int max_leaf, max_depth;
+
+    int build(int first, int count, int depth) {
+        int id = (int)tmp.size();
+        tmp.emplace_back();
+        Box box, cbox;
+        for (int i = 0; i < count; i++) {
+            int p = order[first + i];
+            box.grow(prims[p].lo, prims[p].hi);
+            cbox.grow(&centroid[3 * p], &centroid[3 * p]);
+        }
+        tmp[id].box = box; tmp[id].depth = depth;
+        auto make_leaf = [&]() { tmp[id].first = first; tmp[id].count = count; return id; };
+        if (count <= 1 || depth >= max_depth) return make_leaf();
+        // binned SAH over the three axes
+        constexpr int kBins = 16;
+        float best_cost = std::numeric_limits<float>::infinity(); int best_axis = -1, best_bin = -1;
+        for (int axis = 0; axis < 3; axis++) {
+            float c0 = cbox.lo[axis], c1 = cbox.hi[axis];
+            if (!(c1 > c0)) continue;
+            Box bins[kBins]; int counts[kBins] = {0};
+            float scale = kBins / (c1 - c0);
+            for (int i = 0; i < count; i++) {
+                int p = order[first + i];
+                int b = std::min(kBins - 1, std::max(0, (int)((centroid[3 * p + axis] - c0) * scale)));
+                bins[b].grow(prims[p].lo, prims[p].hi); counts[b]++;
+            }
+            float right_area[kBins]; int right_count[kBins];
+            Box acc; int n = 0;
+            for (int b = kBins - 1; b > 0; b--) { acc.grow(bins[b]); n += counts[b]; right_area[b] = acc.half_area(); right_count[b] = n; }
+            acc = Box(); n = 0;
+            for (int b = 0; b < kBins - 1; b++) {
+                acc.grow(bins[b]); n += counts[b];
+                if (n == 0 || right_count[b + 1] == 0) continue;
+                float cost = acc.half_area() * n + right_area[b + 1] * right_count[b + 1];
+                if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; }
+            }
+        }
+        const float leaf_cost = box.half_area() * count;
+        int mid;
+        if (best_axis < 0) {
+            if (count <= max_leaf) return make_leaf();
+            mid = first + count / 2;  // all centroids coincide: split the list in half
+        } else {
+            // 1.0 box-test cost vs 1.2 primitive-test cost, both children boxes are tested in the parent
+            const float split_cost = 1.0f * box.half_area() + best_cost * 1.2f;
+            if (count <= max_leaf && leaf_cost * 1.2f <= split_cost) return make_leaf();
+            float c0 = cbox.lo[best_axis], c1 = cbox.hi[best_axis];
+            float scale = kBins / (c1 - c0);
+            auto it = std::partition(order.begin() + first, order.begin() + first + count, [&](int p) {
+                int b = std::min(kBins - 1, std::max(0, (int)((centroid[3 * p + best_axis] - c0) * scale)));
+                return b <= best_bin;
+            });
+            mid = (int)(it - order.begin());
+            if (mid == first || mid == first + count) mid = first + count / 2;
+        }
+        int l = build(first, mid - first, depth + 1);
+        int r = build(mid, first + count - mid, depth + 1);
+        tmp[id].left = l; tmp[id].right = r;
+        return id;
+    }
+};
+
+} // namespace
+
+void build_bvh(const std::vector<BuildPrim> &prims, int max_leaf, int max_depth,
+               std::vector<ljd::DNode> &nodes, std::vector<int> &leaf_order, int &depth_out) {
+    nodes.clear(); leaf_order.clear(); depth_out = 0;
+    const int n = (int)prims.size();
+    auto empty_child = [](float *lo, float *hi) { for (int k = 0; k < 3; k++) { lo[k] = std::numeric_limits<float>::infinity(); hi[k] = -std::numeric_limits<float>::infinity(); } };
+    if (n == 0) {
+        ljd::DNode nd{}; empty_child(nd.lo0, nd.hi0); empty_child(nd.lo1, nd.hi1); nd.c0 = nd.c1 = -1; nd.n0 = nd.n1 = 0;
+        nodes.push_back(nd);
+        return;
+    }
+    Builder b{prims, {}, {}, {}, max_leaf, max_depth};
+    b.order.resize(n); b.centroid.resize(3 * (size_t)n);
+    for (int i = 0; i < n; i++) { b.order[i] = i; for (int k = 0; k < 3; k++) b.centroid[3 * i + k] = 0.5f * (prims[i].lo[k] + prims[i].hi[k]); }
+    b.tmp.reserve(2 * (size_t)n);
+    int root = b.build(0, n, 0);
+    // A leaf that ended up larger than max_leaf because of the depth cap stays as it is: correctness first.
+    leaf_order = b.order;
+    // breadth-first numbering of the inner nodes; leaves are folded into their parent's record
+    std::vector<int> bfs;  // TmpNode ids of inner nodes in output order
+    std::vector<int> out_index(b.tmp.size(), -1);
+    auto is_leaf = [&](int id) { return b.tmp[id].left < 0; };
+    if (is_leaf(root)) {
+        ljd::DNode nd{};
+        memcpy(nd.lo0, b.tmp[root].box.lo, 12); memcpy(nd.hi0, b.tmp[root].box.hi, 12);
+        nd.c0 = ~b.tmp[root].first; nd.n0 = b.tmp[root].count;
+        empty_child(nd.lo1, nd.hi1); nd.c1 = -1; nd.n1 = 0;
+        nodes.push_back(nd); depth_out = 1;
+        return;
+    }
+    bfs.push_back(root); out_index[root] = 0;
+    for (size_t h = 0; h < bfs.size(); h++) {
+        const TmpNode &t = b.tmp[bfs[h]];
+        for (int c : {t.left, t.right}) if (!is_leaf(c)) { out_index[c] = (int)bfs.size(); bfs.push_back(c); }
+    }
+    nodes.resize(bfs.size());
+    for (size_t h = 0; h < bfs.size(); h++) {
+        const TmpNode &t = b.tmp[bfs[h]];
+        ljd::DNode nd{};
+        const TmpNode &L = b.tmp[t.left], &R = b.tmp[t.right];
+        memcpy(nd.lo0, L.box.lo, 12); memcpy(nd.hi0, L.box.hi, 12);
+        memcpy(nd.lo1, R.box.lo, 12); memcpy(nd.hi1, R.box.hi, 12);
+        if (is_leaf(t.left)) { nd.c0 = ~L.first; nd.n0 = L.count; } else { nd.c0 = out_index[t.left]; nd.n0 = 0; }
+        if (is_leaf(t.right)) { nd.c1 = ~R.first; nd.n1 = R.count; } else { nd.c1 = out_index[t.right]; nd.n1 = 0; }
+        nodes[h] = nd;
+        depth_out = std::max(depth_out, t.depth + 1);
+    }
+}
+
+} // namespace lj

@@ -1,0 +1,44 @@
+// LjSceneDesc -> flat, pointer-free arrays in the device layouts of device/dtypes.h.
+// This is the host half of the reference's Scene::Scene (scene.cpp:3-53): bounds sphere, per-mesh area tables,
+// envmap table, light table — plus the BVH that replaces rtcCommitScene.  Pure C++ (no HIP), so the CPU test
+// suite can check the flattened tables against the golden vectors without a GPU.
+#pragma once
+#include "../device/dtypes.h"
+#include "host_scene.h"
+#include <vector>
+
+namespace lj {
+
+struct FlatScene {
+    ljd::DCamera cam{};
+    std::vector<ljd::DNode> nodes;
+    std::vector<ljd::DPrim> leaf_prims;
+    std::vector<ljd::DPrimShade> prims;
+    std::vector<ljd::DSphere> spheres;
+    std::vector<ljd::DMaterial> materials;
+    std::vector<ljd::DLight> lights;
+    std::vector<float> light_cdf;
+    std::vector<ljd::DLightTri> light_tris;
+    std::vector<float> light_tri_cdf;
+    std::vector<ljd::DImage> images3, images1;
+    std::vector<float> texels;
+    std::vector<float> env_tables;
+    int envmap_light_id = -1, max_depth = -1, rr_depth = 5, spp = 4, integrator = LJ_INTEGRATOR_PATH;
+    int bvh_depth = 0;
+    int64_t n_triangles = 0, n_spheres = 0;
+    double bounds_radius = 0, bounds_center[3] = {0, 0, 0}, shadow_epsilon = 0;
+    // double-precision tables kept for inspection by tests (scene.cpp:47-52)
+    std::vector<double> light_pmf_d, light_cdf_d, light_power_d;
+    // a DScene whose pointers refer to the vectors above (host memory)
+    ljd::DScene host_view() const;
+};
+
+// Throws LjError(LJ_ERR_UNSUPPORTED) for variant alternatives the device path does not implement.
+FlatScene flatten_scene(const LjSceneDesc &d);
+
+// bvh.cpp — binned-SAH BVH2 over padded float boxes; fills nodes (breadth-first) and leaf order.
+struct BuildPrim { float lo[3], hi[3]; };
+void build_bvh(const std::vector<BuildPrim> &prims, int max_leaf, int max_depth,
+               std::vector<ljd::DNode> &nodes, std::vector<int> &leaf_order, int &depth_out);
+
+} // namespace lj

@@ -1,0 +1,55 @@
+// Host-side scene container behind `lj_host_scene`: owns the storage an LjSceneDesc points into.
+// Mirrors what parse_scene() hands to Scene::Scene in the reference (parse_scene.cpp:1122-1131).
+#pragma once
+#include "../../../include/lajolla_hip.h"
+#include "hmath.h"
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace lj {
+
+struct LjError : std::runtime_error {
+    int code;
+    LjError(int c, const std::string &what) : std::runtime_error(what), code(c) {}
+};
+
+struct HostImage {
+    int width = 0, height = 0, channels = 0;
+    std::vector<float> data;
+};
+
+struct HostScene {
+    LjCamera camera{};
+    LjRenderOptions options{};
+    std::vector<LjShape> shapes;
+    std::vector<LjMaterial> materials;
+    std::vector<LjLight> lights;
+    std::vector<HostImage> images3, images1;
+    std::map<std::string, int> image3s_map, image1s_map;  // TexturePool maps (texture.h:13-19)
+    std::vector<double> positions, normals, uvs;
+    std::vector<int32_t> indices;
+    int envmap_light_id = -1;
+    std::string output_filename = "image.exr";
+
+    // filled by finalize()
+    std::vector<LjImage> image3_views, image1_views;
+    LjSceneDesc desc{};
+    void finalize();
+};
+
+// deep copy of a caller-provided description
+HostScene *host_scene_from_desc(const LjSceneDesc &d);
+
+// scene_xml.cpp
+HostScene *parse_scene_xml(const std::string &path);
+
+// mesh_io.cpp — both append one TriangleMesh to the pools and return its LjShape (ids unset)
+LjShape load_obj_mesh(HostScene &hs, const std::string &filename, const M4 &to_world);
+LjShape load_serialized_mesh(HostScene &hs, const std::string &filename, int shape_index, const M4 &to_world);
+
+// image_io.cpp — imread3 / imread1 (image.cpp:28-133)
+HostImage read_image(const std::string &filename, int channels);
+
+} // namespace lj

@@ -1,0 +1,136 @@
+// TEST INFRASTRUCTURE — host build of the *device* headers (device/dshade.h, device/dtrace.h) with g++.
+//
+// There is no GPU in the authoring container, so the float shading / traversal code that the HIP kernels run is
+// also compiled for the CPU here and driven path by path, to debug it against the double-precision oracle before
+// any GPU minute is spent.  This library is built only by the test suite, lives under tests/, is never loaded by
+// the product and is not a fallback: lajolla_public_amd has no code path that reaches it.
+#include "../../lajolla_public_amd/csrc/device/dshade.h"
+#include "../../lajolla_public_amd/csrc/device/dtrace.h"
+#include "../../lajolla_public_amd/csrc/host/flatten.h"
+#include <cstring>
+#include <thread>
+#include <vector>
+
+using namespace ljd;
+
+namespace {
+
+struct HostMem {
+    const DScene &sc;
+    int stack[64];
+    explicit HostMem(const DScene &s) : sc(s) {}
+    DNode node(int i) const { return sc.nodes[i]; }
+    DPrim prim(int i) const { return sc.leaf_prims[i]; }
+    const DSphere &sphere(int s) const { return sc.spheres[s]; }
+    void push(int sp, int v) { stack[sp] = v; }
+    int pop(int sp) const { return stack[sp]; }
+    int max_stack() const { return 64; }
+};
+
+// what k_extend does for one queue slot
+void extend_one(const DScene &sc, PathState &ps) {
+    HostMem mem(sc);
+    RayF ray; ray.ox = ps.org.x; ray.oy = ps.org.y; ray.oz = ps.org.z;
+    int code = 0;
+    if (ps.stfar > 0.0f) {
+        ray.dx = ps.sdir.x; ray.dy = ps.sdir.y; ray.dz = ps.sdir.z; ray.tnear = sc.eps; ray.tfar = ps.stfar;
+        HitRec h;
+        if (!traverse<true>(mem, ray, h)) code |= HIT_VIS_BIT;
+    }
+    float t = 0, u = 0, v = 0;
+    if (!(ps.flags & PF_NO_EXT)) {
+        ray.dx = ps.dir.x; ray.dy = ps.dir.y; ray.dz = ps.dir.z;
+        ray.tnear = ((ps.flags & 0xffffu) == 2u) ? 0.0f : sc.eps; ray.tfar = INFINITY;
+        HitRec h;
+        if (traverse<false>(mem, ray, h)) { code |= (h.gprim + 1); t = h.t; u = h.u; v = h.v; }
+    }
+    ps.ht = t; ps.hu = u; ps.hv = v; ps.hcode = code;
+}
+
+struct Twin { lj::FlatScene flat; DScene view; };
+
+} // namespace
+
+extern "C" {
+
+void *twin_create(const LjSceneDesc *d, char *err, int err_len) {
+    try {
+        Twin *t = new Twin();
+        t->flat = lj::flatten_scene(*d);
+        t->view = t->flat.host_view();
+        return t;
+    } catch (const std::exception &e) {
+        if (err && err_len > 0) { strncpy(err, e.what(), err_len - 1); err[err_len - 1] = 0; }
+        return nullptr;
+    }
+}
+void twin_free(void *t) { delete (Twin *)t; }
+
+void twin_tables(void *tv, double *bounds_radius, double *bounds_center, double *eps, double *light_pmf, double *light_cdf, double *light_power,
+                 int *n_nodes, int *bvh_depth) {
+    Twin *t = (Twin *)tv;
+    *bounds_radius = t->flat.bounds_radius; for (int k = 0; k < 3; k++) bounds_center[k] = t->flat.bounds_center[k];
+    *eps = t->flat.shadow_epsilon;
+    for (size_t i = 0; i < t->flat.light_pmf_d.size(); i++) { light_pmf[i] = t->flat.light_pmf_d[i]; light_power[i] = t->flat.light_power_d[i]; }
+    for (size_t i = 0; i < t->flat.light_cdf_d.size(); i++) light_cdf[i] = t->flat.light_cdf_d[i];
+    *n_nodes = (int)t->flat.nodes.size(); *bvh_depth = t->flat.bvh_depth;
+}
+
+// per-sample radiance over a crop window, same layout as lj_render_samples
+void twin_render_samples(void *tv, int spp, int max_depth, int use_max_depth, uint64_t seed, int x0, int y0, int x1, int y1, int n_threads, float *out,
+                         unsigned long long *bounces_out) {
+    Twin *t = (Twin *)tv;
+    DScene sc = t->view;
+    if (use_max_depth) sc.max_depth = max_depth;
+    const int w = sc.cam.width, cw = x1 - x0, ch = y1 - y0;
+    std::vector<uint32_t> pixels;
+    for (int y = y0; y < y1; y++) for (int x = x0; x < x1; x++) pixels.push_back((uint32_t)(y * w + x));
+    DPass pass{}; pass.pixel_list = pixels.data(); pass.n_pixels = (uint32_t)pixels.size(); pass.spp = (uint32_t)spp;
+    pass.seed = seed ? seed : 0x853c49e6748fea9bULL; pass.sample_rgb = out;
+    const uint64_t total = (uint64_t)cw * ch * spp;
+    if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+    std::vector<unsigned long long> bounces(n_threads, 0);
+    auto worker = [&](int tid) {
+        ShadeCounters cnt{};
+        for (uint64_t s = tid; s < total; s += n_threads) {
+            PathState ps;
+            generate_path(sc, pass, (uint32_t)s, ps);
+            for (int step = 0; step < 100000; step++) {
+                extend_one(sc, ps);
+                if (!shade_path(sc, pass, ps, cnt)) break;
+            }
+            out[3 * s] = ps.rad.x; out[3 * s + 1] = ps.rad.y; out[3 * s + 2] = ps.rad.z;
+        }
+        bounces[tid] = cnt.bounces;
+    };
+    std::vector<std::thread> th;
+    for (int i = 1; i < n_threads; i++) th.emplace_back(worker, i);
+    worker(0);
+    for (auto &x : th) x.join();
+    unsigned long long b = 0; for (auto v : bounces) b += v;
+    if (bounces_out) *bounces_out = b;
+}
+
+void twin_intersect(void *tv, int64_t n, const LjRay *rays, LjHit *hits) {
+    Twin *t = (Twin *)tv;
+    const DScene &sc = t->view;
+    HostMem mem(sc);
+    for (int64_t i = 0; i < n; i++) {
+        RayF r; r.ox = rays[i].org[0]; r.oy = rays[i].org[1]; r.oz = rays[i].org[2]; r.dx = rays[i].dir[0]; r.dy = rays[i].dir[1]; r.dz = rays[i].dir[2];
+        r.tnear = rays[i].tnear; r.tfar = rays[i].tfar;
+        HitRec h; LjHit o{0, 0, 0, -1, -1};
+        if (traverse<false>(mem, r, h)) { const DPrimShade &ps = sc.prims[h.gprim]; o = LjHit{h.t, h.u, h.v, ps.shape_id, ps.prim_id}; }
+        hits[i] = o;
+    }
+}
+void twin_occluded(void *tv, int64_t n, const LjRay *rays, uint8_t *occ) {
+    Twin *t = (Twin *)tv;
+    HostMem mem(t->view);
+    for (int64_t i = 0; i < n; i++) {
+        RayF r; r.ox = rays[i].org[0]; r.oy = rays[i].org[1]; r.oz = rays[i].org[2]; r.dx = rays[i].dir[0]; r.dy = rays[i].dir[1]; r.dz = rays[i].dir[2];
+        r.tnear = rays[i].tnear; r.tfar = rays[i].tfar;
+        HitRec h; occ[i] = traverse<true>(mem, r, h) ? 1 : 0;
+    }
+}
+
+} // extern "C"
