@@ -7,19 +7,21 @@
 #include "../host/flatten.h"
 #include "dtypes.h"
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <vector>
 
 namespace ljd {
-bool scene_is_small(int n_nodes, int n_prims, int bvh_depth);
-int large_stack_depth();
-void launch_prepare(DCtrl *c, hipStream_t s);
-void launch_generate(const DScene &sc, const DPass &pass, const DQueue &q, const DCtrl *c, int grid, hipStream_t s);
-void launch_extend(const DScene &sc, const DQueue &q, DCtrl *c, bool small, int grid, hipStream_t s);
-void launch_shade(const DScene &sc, const DPass &pass, const DQueue &qin, const DQueue &qout, DCtrl *c, int grid, hipStream_t s);
+struct ExtendConfig { int stack; int lds_nodes; int lds_prims; size_t smem; uint32_t refill_min, min_descending; };
+struct ShadeConfig { uint32_t prims_bytes, materials_bytes, lights_bytes, light_cdf_bytes, light_tris_bytes, light_tri_cdf_bytes, stage_prims; size_t smem; };
+ShadeConfig shade_config(size_t n_prims, size_t n_materials, size_t n_lights, size_t n_light_tris, size_t n_light_tri_cdf);
+ExtendConfig extend_config(int n_nodes, int n_prims, int bvh_depth);
+int max_stack_depth();
+void launch_extend(const DScene &sc, const DQueue &q, const DBlockState *blocks, uint32_t n_blocks, uint32_t seg, const ExtendConfig &cfg, hipStream_t s);
+void launch_shade(const DScene &sc, const DPass &pass, const DQueue &q, DBlockState *blocks, uint32_t n_blocks, uint32_t seg, const ShadeConfig &cfg, hipStream_t s);
 void launch_resolve(const DPass &pass, uint32_t n_pixels, float *rgb, hipStream_t s);
-void launch_trace_rays(const DScene &sc, const void *rays, long long n, void *hits, unsigned char *occ, bool small, int grid, hipStream_t s);
+void launch_trace_rays(const DScene &sc, const void *rays, long long n, void *hits, unsigned char *occ, const ExtendConfig &cfg, int grid, hipStream_t s);
 }
 
 namespace {
@@ -38,12 +40,12 @@ struct DevBuf {
 };
 
 template <typename T> void upload(DevBuf &b, const std::vector<T> &v, hipStream_t s) {
-    b.alloc(std::max<size_t>(v.size(), 1) * sizeof(T));
+    b.alloc(((std::max<size_t>(v.size(), 1) * sizeof(T)) + 31) & ~(size_t)15);
     if (!v.empty()) HIP_CHECK(hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
 }
 
-constexpr size_t kQueueSlotBytes = 124;
-constexpr int kQueueArrays = 29;
+constexpr size_t kQueueSlotBytes = 128;  // eight 16-byte records per path
+constexpr uint32_t kMaxBlocks = 8192;
 
 } // namespace
 
@@ -52,9 +54,9 @@ struct lj_context {
     hipStream_t stream = nullptr;
     int n_cus = 256;
     // workspace, grown on demand and reused across renders
-    DevBuf queue_mem[2]; uint32_t queue_capacity = 0;
-    DevBuf ctrl, sample_rgb, pixel_list, frame;
-    ljd::DCtrl *ctrl_host = nullptr;  // pinned
+    DevBuf queue_mem; uint32_t queue_capacity = 0;
+    DevBuf blocks, sample_rgb, pixel_list, frame;
+    ljd::DBlockState *blocks_host = nullptr;  // pinned, kMaxBlocks entries
     hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_k0 = nullptr, ev_k1 = nullptr;
 };
 
@@ -63,7 +65,8 @@ struct lj_scene {
     lj::FlatScene flat;  // host copy (tables for lj_scene_info; arrays already uploaded)
     DevBuf nodes, leaf_prims, prims, spheres, materials, lights, light_cdf, light_tris, light_tri_cdf, images3, images1, texels, env_tables;
     ljd::DScene dscene{};
-    bool small = false;
+    ljd::ExtendConfig ecfg{};
+    ljd::ShadeConfig scfg{};
     LjStats stats{};
 };
 
@@ -72,26 +75,20 @@ namespace {
 void set_device(lj_context *ctx) { HIP_CHECK(hipSetDevice(ctx->device)); }
 
 ljd::DQueue carve_queue(void *base, uint32_t cap) {
-    // one allocation, 29 arrays; every array starts on a 256-byte boundary so wave accesses are aligned
+    // one allocation, eight arrays of 16-byte records; hipMalloc returns 256-byte aligned memory and cap is a
+    // multiple of 64, so every array starts on a 1 KiB boundary (one full wave instruction)
     ljd::DQueue q{};
-    char *p = (char *)base;
-    auto take = [&](size_t elem) { void *r = p; size_t bytes = ((size_t)cap * elem + 255) & ~(size_t)255; p += bytes; return r; };
-    q.ox = (float *)take(4); q.oy = (float *)take(4); q.oz = (float *)take(4);
-    q.dx = (float *)take(4); q.dy = (float *)take(4); q.dz = (float *)take(4);
-    q.ht = (float *)take(4); q.hu = (float *)take(4); q.hv = (float *)take(4); q.hprim = (int32_t *)take(4);
-    q.sx = (float *)take(4); q.sy = (float *)take(4); q.sz = (float *)take(4); q.st = (float *)take(4);
-    q.wr = (float *)take(4); q.wg = (float *)take(4); q.wb = (float *)take(4); q.rr = (float *)take(4); q.p2 = (float *)take(4);
-    q.lr = (float *)take(4); q.lg = (float *)take(4); q.lb = (float *)take(4);
-    q.nr = (float *)take(4); q.ng = (float *)take(4); q.nb = (float *)take(4);
-    q.sample = (uint32_t *)take(4); q.rng = (uint64_t *)take(8);
-    q.eta_scale = (float *)take(4); q.spread = (float *)take(4); q.flags = (uint32_t *)take(4);
+    ljd::Rec4 *p = (ljd::Rec4 *)base;
+    auto take = [&]() { ljd::Rec4 *r = p; p += cap; return r; };
+    q.ro = take(); q.rd = take(); q.rs = take(); q.rh = take(); q.rw = take(); q.rl = take(); q.rn = take(); q.rg = take();
     return q;
 }
-size_t queue_bytes(uint32_t cap) { return (size_t)31 * ((((size_t)cap * 4 + 255) & ~(size_t)255)) + 256; }  // 30 arrays, rng counts twice
+size_t queue_bytes(uint32_t cap) { return (size_t)cap * kQueueSlotBytes; }
 
 void ensure_queues(lj_context *ctx, uint32_t cap) {
     if (ctx->queue_capacity >= cap) return;
-    for (int i = 0; i < 2; i++) ctx->queue_mem[i].alloc(queue_bytes(cap));
+    cap = (cap + 63u) & ~63u;
+    ctx->queue_mem.alloc(queue_bytes(cap));
     ctx->queue_capacity = cap;
 }
 
@@ -133,8 +130,8 @@ RenderPlan make_plan(const lj_scene *sc, const LjRenderArgs *a) {
     return p;
 }
 
-// Renders plan.pixels; if rgb_dev != null writes radiance/spp there (other pixels untouched), if samples_dev_out != null
-// the per-sample radiance of every pass is copied to host memory `samples_host` in pixel-list order.
+// Renders plan.pixels; if rgb_dev != null writes radiance/spp there (other pixels untouched), if samples_host != null
+// the per-sample radiance of every pass is copied to host memory in pixel-list order.
 void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *samples_host, hipStream_t stream, bool timing) {
     lj_context *ctx = sc->ctx;
     set_device(ctx);
@@ -147,66 +144,79 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
     const uint64_t max_samples_pass = (uint64_t)1 << 27;
     uint64_t pix_per_pass = std::max<uint64_t>(1, max_samples_pass / (uint64_t)plan.spp);
     pix_per_pass = std::min<uint64_t>(pix_per_pass, n_pix);
-    const uint32_t cap = (uint32_t)std::min<uint64_t>(plan.pool, pix_per_pass * (uint64_t)plan.spp);
-    ensure_queues(ctx, cap);
-    ljd::DQueue q[2] = {carve_queue(ctx->queue_mem[0].p, ctx->queue_capacity), carve_queue(ctx->queue_mem[1].p, ctx->queue_capacity)};
-    if (ctx->sample_rgb.bytes < pix_per_pass * plan.spp * 12) ctx->sample_rgb.alloc(pix_per_pass * plan.spp * 12);
+    // queue geometry: n_blocks workgroups x seg slots; workgroup b owns slots [b*seg, (b+1)*seg)
+    const uint64_t pass_samples_max = pix_per_pass * (uint64_t)plan.spp;
+    uint32_t pool = (uint32_t)std::min<uint64_t>(plan.pool, std::max<uint64_t>(pass_samples_max, 256));
+    uint32_t n_blocks = std::min<uint32_t>(kMaxBlocks, std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)ctx->n_cus * 8, pool / 256)));
+    uint32_t seg = ((pool + n_blocks - 1) / n_blocks + 255u) & ~255u;
+    const uint32_t n_slots = n_blocks * seg;
+    ensure_queues(ctx, n_slots);
+    ljd::DQueue q = carve_queue(ctx->queue_mem.p, ctx->queue_capacity);
+    if (ctx->sample_rgb.bytes < pass_samples_max * 12) ctx->sample_rgb.alloc(pass_samples_max * 12);
     if (ctx->pixel_list.bytes < n_pix * 4) ctx->pixel_list.alloc(n_pix * 4);
     HIP_CHECK(hipMemcpyAsync(ctx->pixel_list.p, plan.pixels.data(), n_pix * 4, hipMemcpyHostToDevice, stream));
-    ljd::DCtrl *dctrl = (ljd::DCtrl *)ctx->ctrl.p;
-    const int grid_stream = ctx->n_cus * 4, grid_extend = ctx->n_cus * (sc->small ? 4 : 2);
+    ljd::DBlockState *dblocks = (ljd::DBlockState *)ctx->blocks.p;
     HIP_CHECK(hipEventRecord(ctx->ev_begin, stream));
     double extend_ms = 0, shade_ms = 0;
     for (uint64_t p0 = 0; p0 < n_pix; p0 += pix_per_pass) {
         const uint64_t np = std::min<uint64_t>(pix_per_pass, n_pix - p0);
+        const uint64_t total = np * (uint64_t)plan.spp;
         ljd::DPass pass{};
         pass.pixel_list = (const uint32_t *)ctx->pixel_list.p + p0; pass.n_pixels = (uint32_t)np; pass.spp = (uint32_t)plan.spp;
         pass.seed = plan.seed; pass.sample_rgb = (float *)ctx->sample_rgb.p;
-        ljd::DCtrl init{}; init.total_samples = np * (uint64_t)plan.spp; init.capacity = cap;
-        init.bounce_iterations = st.bounce_iterations; init.rays_closest = st.rays_closest; init.rays_shadow = st.rays_shadow;
-        init.samples_done = 0; init.steps = (uint32_t)st.wavefront_steps; init.path_steps = 0;
-        *ctx->ctrl_host = init;
-        HIP_CHECK(hipMemcpyAsync(dctrl, ctx->ctrl_host, sizeof(ljd::DCtrl), hipMemcpyHostToDevice, stream));
-        HIP_CHECK(hipStreamSynchronize(stream));
-        int cur = 0;
-        uint64_t path_steps_total = 0;
-        for (int guard = 0; guard < (1 << 22); guard++) {
-            // a batch of steps runs without any host round trip; the device-side control block carries all counts
-            const int batch = 8;
+        // contiguous sample ranges per workgroup, multiples of 64 so that a wave's first samples share a pixel
+        {
+            uint64_t per = ((total + n_blocks - 1) / n_blocks + 63) & ~(uint64_t)63;
+            for (uint32_t b = 0; b < n_blocks; b++) {
+                ljd::DBlockState bs{};
+                uint64_t lo = std::min<uint64_t>(total, (uint64_t)b * per), hi = std::min<uint64_t>(total, (uint64_t)(b + 1) * per);
+                bs.next_sample = (uint32_t)lo; bs.end_sample = (uint32_t)hi;
+                ctx->blocks_host[b] = bs;
+            }
+            HIP_CHECK(hipMemcpyAsync(dblocks, ctx->blocks_host, sizeof(ljd::DBlockState) * n_blocks, hipMemcpyHostToDevice, stream));
+        }
+        // step 0 is a shade over empty segments: it only generates camera rays
+        ljd::launch_shade(ds, pass, q, dblocks, n_blocks, seg, sc->scfg, stream);
+        bool done = false;
+        for (int guard = 0; guard < (1 << 20) && !done; guard++) {
+            const int batch = 8;  // steps per host round trip; all per-step state lives on the device
             for (int b = 0; b < batch; b++) {
-                ljd::launch_prepare(dctrl, stream);
-                ljd::launch_generate(ds, pass, q[cur], dctrl, grid_stream, stream);
                 if (timing) HIP_CHECK(hipEventRecord(ctx->ev_k0, stream));
-                ljd::launch_extend(ds, q[cur], dctrl, sc->small, grid_extend, stream);
-                if (timing) { HIP_CHECK(hipEventRecord(ctx->ev_k1, stream)); }
-                ljd::launch_shade(ds, pass, q[cur], q[cur ^ 1], dctrl, grid_stream, stream);
+                ljd::launch_extend(ds, q, dblocks, n_blocks, seg, sc->ecfg, stream);
+                if (timing) HIP_CHECK(hipEventRecord(ctx->ev_k1, stream));
+                ljd::launch_shade(ds, pass, q, dblocks, n_blocks, seg, sc->scfg, stream);
                 if (timing) {
                     HIP_CHECK(hipEventRecord(ctx->ev_end, stream));
                     HIP_CHECK(hipEventSynchronize(ctx->ev_end));
                     float a = 0, c = 0;
                     HIP_CHECK(hipEventElapsedTime(&a, ctx->ev_k0, ctx->ev_k1)); HIP_CHECK(hipEventElapsedTime(&c, ctx->ev_k1, ctx->ev_end));
-                    extend_ms += a; shade_ms += c; st.extend_launches++; st.shade_launches++;
+                    extend_ms += a; shade_ms += c;
                 }
-                cur ^= 1;
+                st.extend_launches++; st.shade_launches++; st.wavefront_steps++;
             }
             HIP_CHECK(hipGetLastError());
-            HIP_CHECK(hipMemcpyAsync(ctx->ctrl_host, dctrl, sizeof(ljd::DCtrl), hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipMemcpyAsync(ctx->blocks_host, dblocks, sizeof(ljd::DBlockState) * n_blocks, hipMemcpyDeviceToHost, stream));
             HIP_CHECK(hipStreamSynchronize(stream));
-            const ljd::DCtrl &c = *ctx->ctrl_host;
-            path_steps_total = c.path_steps;
-            if (c.next_sample >= c.total_samples && c.n_out == 0) break;
+            uint64_t alive = 0;
+            for (uint32_t b = 0; b < n_blocks; b++) alive += ctx->blocks_host[b].count;
+            done = alive == 0;
         }
-        const ljd::DCtrl &c = *ctx->ctrl_host;
-        if (c.samples_done != c.total_samples)
-            throw LjError(LJ_ERR_INTERNAL, "wavefront loop ended with " + std::to_string(c.samples_done) + " of " + std::to_string(c.total_samples) + " samples finished");
-        st.samples += c.total_samples; st.bounce_iterations = c.bounce_iterations; st.rays_closest = c.rays_closest; st.rays_shadow = c.rays_shadow;
-        st.wavefront_steps = c.steps;
-        // algorithmic queue traffic: extend reads 48 + writes 16 per path-step, shade reads 108 and writes 108 per survivor
-        st.extend_bytes += path_steps_total * 64ull;
-        st.shade_bytes += path_steps_total * 108ull + (path_steps_total - c.total_samples) * 108ull + c.total_samples * 12ull;
+        uint64_t samples_done = 0, path_steps = 0;
+        for (uint32_t b = 0; b < n_blocks; b++) {
+            const ljd::DBlockState &bs = ctx->blocks_host[b];
+            samples_done += bs.samples_done; path_steps += bs.path_steps;
+            st.bounce_iterations += bs.bounce_iterations; st.rays_closest += bs.rays_closest; st.rays_shadow += bs.rays_shadow;
+        }
+        if (samples_done != total)
+            throw LjError(LJ_ERR_INTERNAL, "wavefront loop ended with " + std::to_string(samples_done) + " of " + std::to_string(total) + " samples finished");
+        st.samples += total;
+        // algorithmic queue traffic: extend reads ro, rd, rs (48 B) and writes rh (16 B) per live path-step;
+        // shade reads 7 records (112 B) and writes 7 records (112 B) per live path-step, plus 12 B per finished sample
+        st.extend_bytes += path_steps * 64ull;
+        st.shade_bytes += path_steps * 224ull + total * 12ull;
         if (rgb_dev) ljd::launch_resolve(pass, (uint32_t)np, rgb_dev, stream);
         if (samples_host) {
-            HIP_CHECK(hipMemcpyAsync(samples_host + p0 * (uint64_t)plan.spp * 3, ctx->sample_rgb.p, np * (uint64_t)plan.spp * 12, hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipMemcpyAsync(samples_host + p0 * (uint64_t)plan.spp * 3, ctx->sample_rgb.p, total * 12, hipMemcpyDeviceToHost, stream));
             HIP_CHECK(hipStreamSynchronize(stream));
         }
     }
@@ -237,8 +247,8 @@ int lj_context_create(int device_id, lj_context **out) {
             throw LjError(LJ_ERR_DEVICE, std::string("device is ") + prop.gcnArchName + "; this build contains gfx950 code objects only");
         ctx->n_cus = prop.multiProcessorCount;
         HIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-        ctx->ctrl.alloc(sizeof(ljd::DCtrl));
-        HIP_CHECK(hipHostMalloc((void **)&ctx->ctrl_host, sizeof(ljd::DCtrl), hipHostMallocDefault));
+        ctx->blocks.alloc(sizeof(ljd::DBlockState) * kMaxBlocks);
+        HIP_CHECK(hipHostMalloc((void **)&ctx->blocks_host, sizeof(ljd::DBlockState) * kMaxBlocks, hipHostMallocDefault));
         HIP_CHECK(hipEventCreate(&ctx->ev_begin)); HIP_CHECK(hipEventCreate(&ctx->ev_end));
         HIP_CHECK(hipEventCreate(&ctx->ev_k0)); HIP_CHECK(hipEventCreate(&ctx->ev_k1));
         *out = ctx.release();
@@ -249,7 +259,7 @@ void lj_context_destroy(lj_context *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
-    if (ctx->ctrl_host) (void)hipHostFree(ctx->ctrl_host);
+    if (ctx->blocks_host) (void)hipHostFree(ctx->blocks_host);
     for (hipEvent_t e : {ctx->ev_begin, ctx->ev_end, ctx->ev_k0, ctx->ev_k1}) if (e) (void)hipEventDestroy(e);
     delete ctx;
 }
@@ -275,9 +285,12 @@ int lj_scene_upload(lj_context *ctx, const LjSceneDesc *desc, lj_scene **out) {
         d.light_cdf = (const float *)sc->light_cdf.p; d.light_tris = (const ljd::DLightTri *)sc->light_tris.p; d.light_tri_cdf = (const float *)sc->light_tri_cdf.p;
         d.images3 = (const ljd::DImage *)sc->images3.p; d.images1 = (const ljd::DImage *)sc->images1.p; d.texels = (const float *)sc->texels.p; d.env_tables = (const float *)sc->env_tables.p;
         sc->dscene = d;
-        sc->small = ljd::scene_is_small((int)F.nodes.size(), (int)F.leaf_prims.size(), F.bvh_depth);
-        if (!sc->small && F.bvh_depth > ljd::large_stack_depth())
+        if (F.bvh_depth > ljd::max_stack_depth())
             throw LjError(LJ_ERR_INTERNAL, "BVH depth " + std::to_string(F.bvh_depth) + " exceeds the traversal stack");
+        sc->ecfg = ljd::extend_config((int)F.nodes.size(), (int)F.leaf_prims.size(), F.bvh_depth);
+        if (const char *e = getenv("LJ_TUNE_REFILL")) sc->ecfg.refill_min = (uint32_t)atoi(e);
+        if (const char *e = getenv("LJ_TUNE_MINDESC")) sc->ecfg.min_descending = (uint32_t)atoi(e);
+        sc->scfg = ljd::shade_config(F.prims.size(), F.materials.size(), F.lights.size(), F.light_tris.size(), F.light_tri_cdf.size());
         *out = sc.release();
     });
 }
@@ -338,7 +351,7 @@ static int trace_batch(lj_scene *scene, int64_t n, const LjRay *rays_host, LjHit
         out.alloc((size_t)n * (hits_host ? sizeof(LjHit) : 1));
         HIP_CHECK(hipMemcpyAsync(rays.p, rays_host, (size_t)n * sizeof(LjRay), hipMemcpyHostToDevice, ctx->stream));
         int grid = (int)std::min<int64_t>((n + 255) / 256, ctx->n_cus * 4);
-        ljd::launch_trace_rays(scene->dscene, rays.p, n, hits_host ? out.p : nullptr, hits_host ? nullptr : (unsigned char *)out.p, scene->small, grid, ctx->stream);
+        ljd::launch_trace_rays(scene->dscene, rays.p, n, hits_host ? out.p : nullptr, hits_host ? nullptr : (unsigned char *)out.p, scene->ecfg, grid, ctx->stream);
         HIP_CHECK(hipGetLastError());
         if (hits_host) HIP_CHECK(hipMemcpyAsync(hits_host, out.p, (size_t)n * sizeof(LjHit), hipMemcpyDeviceToHost, ctx->stream));
         else HIP_CHECK(hipMemcpyAsync(occ_host, out.p, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));

@@ -100,7 +100,7 @@ LJ_HD bool traverse(Mem &mem, const RayF &ray, HitRec &best) {
             const int c = side ? nd.c1 : nd.c0;
             const bool h = side ? h1 : h0;
             if (!h || c >= 0) continue;
-            const int first = ~c, count = side ? nd.n1 : nd.n0;
+            const int first = (~c) >> 3, count = ((~c) & 7) + 1;
             for (int k = 0; k < count; k++) {
                 const DPrim p = mem.prim(first + k);
                 if (p.kind == 0) {

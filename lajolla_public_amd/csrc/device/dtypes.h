@@ -12,7 +12,8 @@
 namespace ljd {
 
 // ---- BVH2, both child boxes stored in the parent (one 64-byte record per traversal step).
-// child >= 0: inner node index.  child < 0: leaf, prims [~child, ~child + count) of the leaf-ordered prim array.
+// child >= 0: inner node index.  child < 0: leaf; ~child = first * 8 + (count - 1) addresses prims
+// [first, first + count) of the leaf-ordered prim array (count <= 8).  n0 / n1 repeat the counts.
 // An empty child has lo = +inf, hi = -inf.
 struct DNode {
     float lo0[3]; int32_t c0;
@@ -110,37 +111,36 @@ struct DScene {
     float init_spread;               // 0.25 / max(w, h)  (ray.h:35-37)
 };
 
-// ---- wavefront path queue: structure of arrays, one slot per in-flight path
+// ---- wavefront path queue: one slot per in-flight path, stored as eight arrays of 16-byte records so that every
+// access is a full-width dwordx4 load/store (1 KiB per wave instruction) and each kernel touches only the
+// records it needs.
+struct alignas(16) Rec4 { float x, y, z, w; };
 struct DQueue {
-    float *ox, *oy, *oz;        // ray origin = position of the vertex the path left (12 B)
-    float *dx, *dy, *dz;        // ray direction (12 B)
-    float *ht, *hu, *hv;        // hit of the extension ray: t, barycentrics (12 B)
-    int32_t *hprim;             // global primitive id, -1 = miss; bit 30 set = pending shadow ray is unoccluded (4 B)
-    float *sx, *sy, *sz, *st;   // pending NEE shadow ray: direction, tfar (<= 0: none) (16 B)
-    float *wr, *wg, *wb;        // W = throughput * f / p2(solid angle) of the sampled direction (12 B)
-    float *rr;                  // Russian-roulette survival probability applied when the path continues (4 B)
-    float *p2;                  // solid-angle pdf of the sampled direction; < 0 on camera rays (no MIS) (4 B)
-    float *lr, *lg, *lb;        // accumulated radiance (12 B)
-    float *nr, *ng, *nb;        // pending NEE contribution throughput*C1*w1, added when the shadow ray is clear (12 B)
-    uint32_t *sample;           // sample id inside this pass (4 B)
-    uint64_t *rng;              // pcg32 state; inc is derived from the stream id (8 B)
-    float *eta_scale, *spread;  // eta_scale (path_tracing.h:53), ray_diff.spread (8 B)
-    uint32_t *flags;            // bits 0-15 num_vertices of the iteration that sampled the ray; bit 16 dying after hit
-                                // accounting; bit 17 no extension ray (only the pending NEE remains) (4 B)
+    Rec4 *ro;   // ray origin xyz = position of the vertex the path left | w: tfar of the pending NEE shadow ray (<= 0: none)
+    Rec4 *rd;   // extension-ray direction xyz                          | w: flags (bit pattern, see PF_*)
+    Rec4 *rs;   // pending NEE shadow-ray direction xyz                 | w: unused
+    Rec4 *rh;   // hit of the extension ray: t, u, v                    | w: code = (global prim id + 1) | HIT_VIS_BIT
+    Rec4 *rw;   // W = throughput * f / p2(solid angle)                 | w: rr, the Russian-roulette survival probability
+    Rec4 *rl;   // accumulated radiance                                 | w: eta_scale (path_tracing.h:53)
+    Rec4 *rn;   // pending NEE contribution throughput * C1 * w1        | w: ray_diff.spread
+    Rec4 *rg;   // x: sample id, y/z: pcg32 state (lo, hi)  (bit patterns) | w: p2, solid-angle pdf of the sampled direction (< 0: camera ray)
 };
-// bytes per slot: 124
+// bytes per slot: 128.  extend reads ro, rd, rs (48 B) and writes rh (16 B); shade reads ro, rd, rh, rw, rl, rn, rg
+// (112 B) and writes ro, rd, rs, rw, rl, rn, rg (112 B) for every surviving path.
 
+// flags: bits 0-15 num_vertices of the iteration that sampled the ray (2 on camera rays); bit 16: Russian roulette
+// said stop (finish after the hit accounting); bit 17: no extension ray (only the pending NEE remains)
 enum : uint32_t { PF_DYING = 1u << 16, PF_NO_EXT = 1u << 17 };
 enum : int32_t { HIT_VIS_BIT = 1 << 30 };
 
-struct DCtrl {
-    uint32_t n_in;        // paths in the current queue
-    uint32_t n_out;       // survivors appended to the next queue by the shade kernel
-    uint32_t n_new;       // camera samples the generate kernel appends this step
-    uint32_t gen_offset;  // first free slot for them
-    uint64_t next_sample, total_samples, gen_base;
-    uint32_t capacity, steps;
-    // counters (LjStats)
+// Per-workgroup bookkeeping.  Workgroup b owns queue slots [b * seg, (b + 1) * seg) — of which the first `count` hold
+// live paths — and the camera samples [next_sample, end_sample).  The shade kernel compacts its survivors to the
+// front of the segment (stable, in place) and appends the workgroup's next camera samples behind them, so every
+// segment stays dense and full without any grid-wide atomic.  Only workgroup b touches entry b.
+struct DBlockState {
+    uint32_t next_sample, end_sample;   // sample ids inside the pass
+    uint32_t count;                     // live paths at the front of the segment
+    uint32_t _pad;
     unsigned long long bounce_iterations, rays_closest, rays_shadow, samples_done, path_steps;
 };
 

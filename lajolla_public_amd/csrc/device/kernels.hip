@@ -1,12 +1,14 @@
 // gfx950 kernels of the wavefront integrator.  Written for wave64 / 256-thread workgroups / 160 KB LDS per CU.
 //
-//   k_prepare   1 thread     : per-step bookkeeping entirely on the device (no host round trip per bounce)
-//   k_generate  grid-stride  : camera samples -> free slots of the current queue      (path_tracing.h:10-14)
 //   k_extend    persistent   : closest hit of the extension ray + any hit of the pending shadow ray over the
-//                              flattened BVH; top of the tree and the per-lane traversal stacks live in LDS
-//                                                                                      (intersection.cpp:7-85)
-//   k_shade     grid-stride  : hit accounting, NEE, BSDF sampling, Russian roulette; survivors are compacted into
-//                              the other queue with one wave-ballot + one atomic per wave (path_tracing.h:58-322)
+//                              flattened BVH.  Persistent waves walk a slice of the queue; a lane whose rays are done
+//                              pulls the next path instead of idling until the slowest lane of the wave finishes
+//                              (while-while traversal with dynamic refill).  Top of the tree, leaf primitives of
+//                              small scenes and the per-lane traversal stacks live in LDS.  (intersection.cpp:7-85)
+//   k_shade     block/segment: hit accounting, NEE, BSDF sampling, Russian roulette (path_tracing.h:58-322).  Each
+//                              workgroup owns one segment of the queue: survivors are compacted to the front of the
+//                              segment in order (wave ballots + a 4-entry LDS scan), then the workgroup's next camera
+//                              samples (path_tracing.h:10-14) are appended behind them.  No grid-wide atomic exists.
 //   k_resolve   wave/pixel   : fixed-order sum of the per-sample radiance -> radiance / spp (render.cpp:94)
 //   k_trace_rays             : batched intersect()/occluded() for the parity tests
 #include <hip/hip_runtime.h>
@@ -16,113 +18,209 @@
 namespace ljd {
 
 constexpr int kBlock = 256;
+#define LJ_LDS __attribute__((address_space(3)))
+typedef float v4f __attribute__((ext_vector_type(4)));  // builtin vector: assignable across address spaces
 
-// ---------------------------------------------------------------- queue <-> registers
+__device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
+__device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
+
+// ---------------------------------------------------------------- queue <-> registers (16-byte records)
 __device__ __forceinline__ void q_load_for_shade(const DQueue &q, uint32_t i, PathState &ps) {
-    ps.org = mk3(q.ox[i], q.oy[i], q.oz[i]); ps.dir = mk3(q.dx[i], q.dy[i], q.dz[i]);
-    ps.ht = q.ht[i]; ps.hu = q.hu[i]; ps.hv = q.hv[i]; ps.hcode = q.hprim[i];
-    ps.W = mk3(q.wr[i], q.wg[i], q.wb[i]); ps.rr = q.rr[i]; ps.p2 = q.p2[i];
-    ps.rad = mk3(q.lr[i], q.lg[i], q.lb[i]); ps.nee = mk3(q.nr[i], q.ng[i], q.nb[i]);
-    ps.sample = q.sample[i]; ps.rng = q.rng[i];
-    ps.eta_scale = q.eta_scale[i]; ps.spread = q.spread[i]; ps.flags = q.flags[i];
+    const Rec4 ro = q.ro[i], rd = q.rd[i], rh = q.rh[i], rw = q.rw[i], rl = q.rl[i], rn = q.rn[i], rg = q.rg[i];
+    ps.org = mk3(ro.x, ro.y, ro.z); ps.dir = mk3(rd.x, rd.y, rd.z); ps.flags = f2u(rd.w);
+    ps.ht = rh.x; ps.hu = rh.y; ps.hv = rh.z; ps.hcode = (int32_t)f2u(rh.w);
+    ps.W = mk3(rw.x, rw.y, rw.z); ps.rr = rw.w;
+    ps.rad = mk3(rl.x, rl.y, rl.z); ps.eta_scale = rl.w;
+    ps.nee = mk3(rn.x, rn.y, rn.z); ps.spread = rn.w;
+    ps.sample = f2u(rg.x); ps.rng = (uint64_t)f2u(rg.y) | ((uint64_t)f2u(rg.z) << 32); ps.p2 = rg.w;
     ps.sdir = mk3(0, 0, 0); ps.stfar = 0.0f;
 }
+__device__ __forceinline__ Rec4 mk4(float x, float y, float z, float w) { Rec4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
 __device__ __forceinline__ void q_store(const DQueue &q, uint32_t i, const PathState &ps) {
-    q.ox[i] = ps.org.x; q.oy[i] = ps.org.y; q.oz[i] = ps.org.z;
-    q.dx[i] = ps.dir.x; q.dy[i] = ps.dir.y; q.dz[i] = ps.dir.z;
-    q.sx[i] = ps.sdir.x; q.sy[i] = ps.sdir.y; q.sz[i] = ps.sdir.z; q.st[i] = ps.stfar;
-    q.wr[i] = ps.W.x; q.wg[i] = ps.W.y; q.wb[i] = ps.W.z; q.rr[i] = ps.rr; q.p2[i] = ps.p2;
-    q.lr[i] = ps.rad.x; q.lg[i] = ps.rad.y; q.lb[i] = ps.rad.z;
-    q.nr[i] = ps.nee.x; q.ng[i] = ps.nee.y; q.nb[i] = ps.nee.z;
-    q.sample[i] = ps.sample; q.rng[i] = ps.rng;
-    q.eta_scale[i] = ps.eta_scale; q.spread[i] = ps.spread; q.flags[i] = ps.flags;
+    q.ro[i] = mk4(ps.org.x, ps.org.y, ps.org.z, ps.stfar);
+    q.rd[i] = mk4(ps.dir.x, ps.dir.y, ps.dir.z, u2f(ps.flags));
+    q.rs[i] = mk4(ps.sdir.x, ps.sdir.y, ps.sdir.z, 0.0f);
+    q.rw[i] = mk4(ps.W.x, ps.W.y, ps.W.z, ps.rr);
+    q.rl[i] = mk4(ps.rad.x, ps.rad.y, ps.rad.z, ps.eta_scale);
+    q.rn[i] = mk4(ps.nee.x, ps.nee.y, ps.nee.z, ps.spread);
+    q.rg[i] = mk4(u2f(ps.sample), u2f((uint32_t)ps.rng), u2f((uint32_t)(ps.rng >> 32)), ps.p2);
 }
 
-// ---------------------------------------------------------------- step bookkeeping
-__global__ void k_prepare(DCtrl *c) {
-    const uint32_t n_in = c->n_out;  // survivors written by the previous shade into what is now the current queue
-    const uint64_t remaining = c->total_samples - c->next_sample;
-    const uint32_t room = c->capacity - n_in;
-    const uint32_t n_new = (uint32_t)(remaining < (uint64_t)room ? remaining : (uint64_t)room);
-    c->gen_base = c->next_sample; c->gen_offset = n_in; c->n_new = n_new;
-    c->next_sample += n_new;
-    c->n_in = n_in + n_new; c->n_out = 0;
-    c->steps += (n_in + n_new) ? 1u : 0u;
-    c->path_steps += n_in + n_new;
-}
-
-__global__ void __launch_bounds__(kBlock) k_generate(DScene sc, DPass pass, DQueue q, const DCtrl *c) {
-    const uint32_t n_new = c->n_new, off = c->gen_offset;
-    const uint64_t base = c->gen_base;
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_new; i += gridDim.x * kBlock) {
-        PathState ps;
-        generate_path(sc, pass, (uint32_t)(base + i), ps);
-        q_store(q, off + i, ps);
-    }
-}
-
-// ---------------------------------------------------------------- extend: BVH traversal with LDS-staged tree top
-template <int LDS_NODES, int LDS_PRIMS, int STACK>
-struct LdsMem {
-    const DNode *gnodes; const DPrim *gprims; const DSphere *spheres;
-    const DNode *lnodes; const DPrim *lprims;
-    int n_lnodes, n_lprims;
-    int *stack;  // this lane's column: stack[level * kBlock]
-    __device__ __forceinline__ DNode node(int i) const { return i < n_lnodes ? lnodes[i] : gnodes[i]; }
-    __device__ __forceinline__ DPrim prim(int i) const { return i < n_lprims ? lprims[i] : gprims[i]; }
-    __device__ __forceinline__ const DSphere &sphere(int s) const { return spheres[s]; }
-    __device__ __forceinline__ void push(int sp, int v) { stack[sp * kBlock] = v; }
-    __device__ __forceinline__ int pop(int sp) const { return stack[sp * kBlock]; }
-    __device__ __forceinline__ int max_stack() const { return STACK; }
+// ---------------------------------------------------------------- extend
+// LDS image (dynamic): [ per-lane stacks: STACK x 256 ints ][ first n_lnodes BVH nodes ][ first n_lprims leaf prims ]
+// Nodes are stored breadth-first, so a prefix of the node array is the top of the tree.
+struct TreeView {
+    const v4f *gnodes; const v4f *gprims; const DSphere *spheres;
+    const LJ_LDS v4f *lnodes; const LJ_LDS v4f *lprims;
+    LJ_LDS int *stack;  // this lane's column; level l lives at stack[l * kBlock]
+    int n_lnodes, n_lprims, node_stride, prim_stride;
 };
 
-template <int LDS_NODES, int LDS_PRIMS, int STACK>
-__device__ __forceinline__ void stage_tree(const DScene &sc, DNode *lnodes, DPrim *lprims, int &n_lnodes, int &n_lprims) {
-    // cooperative copy, 16 bytes per lane per step (nodes are stored breadth-first, so a prefix is the top of the tree)
-    n_lnodes = sc.n_nodes < LDS_NODES ? sc.n_nodes : LDS_NODES;
-    n_lprims = sc.n_prims <= LDS_PRIMS ? sc.n_prims : 0;  // primitives only when the whole scene fits
-    const float4 *src = reinterpret_cast<const float4 *>(sc.nodes);
-    float4 *dst = reinterpret_cast<float4 *>(lnodes);
-    for (int i = threadIdx.x; i < n_lnodes * 4; i += kBlock) dst[i] = src[i];
-    src = reinterpret_cast<const float4 *>(sc.leaf_prims); dst = reinterpret_cast<float4 *>(lprims);
-    for (int i = threadIdx.x; i < n_lprims * 3; i += kBlock) dst[i] = src[i];
+extern __shared__ __attribute__((aligned(16))) v4f lj_smem[];
+
+template <int STACK>
+__device__ __forceinline__ TreeView stage_tree(const DScene &sc, int lds_nodes, int lds_prims) {
+    TreeView tv;
+    LJ_LDS v4f *base = (LJ_LDS v4f *)lj_smem;
+    tv.stack = (LJ_LDS int *)base + threadIdx.x;
+    LJ_LDS v4f *ln = base + (STACK * kBlock) / 4;
+    LJ_LDS v4f *lp = ln + lds_nodes * 4;
+    tv.n_lnodes = sc.n_nodes < lds_nodes ? sc.n_nodes : lds_nodes;
+    tv.n_lprims = sc.n_prims < lds_prims ? sc.n_prims : lds_prims;
+    tv.node_stride = lds_nodes; tv.prim_stride = lds_prims;
+    // The LDS image is transposed: quarter k of node i sits at ln[k * lds_nodes + i].  Lanes that fetch different
+    // nodes then hit different 16-byte bank slots (a 64-byte stride would put every node on the same four).
+    const v4f *src = reinterpret_cast<const v4f *>(sc.nodes);
+    for (int i = threadIdx.x; i < tv.n_lnodes * 4; i += kBlock) ln[(i & 3) * lds_nodes + (i >> 2)] = src[i];
+    src = reinterpret_cast<const v4f *>(sc.leaf_prims);
+    for (int i = threadIdx.x; i < tv.n_lprims * 3; i += kBlock) lp[(i % 3) * lds_prims + (i / 3)] = src[i];
     __syncthreads();
+    tv.gnodes = reinterpret_cast<const v4f *>(sc.nodes); tv.gprims = reinterpret_cast<const v4f *>(sc.leaf_prims);
+    tv.spheres = sc.spheres; tv.lnodes = ln; tv.lprims = lp;
+    return tv;
 }
 
-template <int LDS_NODES, int LDS_PRIMS, int STACK>
-__global__ void __launch_bounds__(kBlock) k_extend(DScene sc, DQueue q, DCtrl *c) {
-    __shared__ __attribute__((aligned(16))) DNode lnodes[LDS_NODES];
-    __shared__ __attribute__((aligned(16))) DPrim lprims[LDS_PRIMS];
-    __shared__ int lstack[STACK * kBlock];
-    LdsMem<LDS_NODES, LDS_PRIMS, STACK> mem;
-    stage_tree<LDS_NODES, LDS_PRIMS, STACK>(sc, lnodes, lprims, mem.n_lnodes, mem.n_lprims);
-    mem.gnodes = sc.nodes; mem.gprims = sc.leaf_prims; mem.spheres = sc.spheres;
-    mem.lnodes = lnodes; mem.lprims = lprims; mem.stack = lstack + threadIdx.x;
-    const uint32_t n = c->n_in;
-    uint32_t n_closest = 0, n_shadow = 0;
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        RayF ray;
-        ray.ox = q.ox[i]; ray.oy = q.oy[i]; ray.oz = q.oz[i];
-        const float stfar = q.st[i];
-        const uint32_t flags = q.flags[i];
-        int code = 0;
-        if (stfar > 0.0f) {  // pending NEE shadow ray [eps, tfar] (path_tracing.h:124-128)
-            ray.dx = q.sx[i]; ray.dy = q.sy[i]; ray.dz = q.sz[i]; ray.tnear = sc.eps; ray.tfar = stfar;
-            HitRec h;
-            if (!traverse<true>(mem, ray, h)) code |= HIT_VIS_BIT;
-            n_shadow++;
+constexpr int kDone = 0x7fffffff;  // "no more work for this ray" marker in `cur`
+
+struct LaneTrav {
+    RayF ray; float ix, iy, iz;
+    HitRec best;
+    int cur, sp;
+};
+
+__device__ __forceinline__ void trav_begin(LaneTrav &L, float tnear, float tfar) {
+    L.ray.tnear = tnear; L.ray.tfar = tfar;
+    L.ix = 1.0f / L.ray.dx; L.iy = 1.0f / L.ray.dy; L.iz = 1.0f / L.ray.dz;
+    L.best.t = tfar; L.best.u = 0.0f; L.best.v = 0.0f; L.best.gprim = -1;
+    L.cur = 0; L.sp = 0;
+}
+__device__ __forceinline__ int trav_pop(const TreeView &tv, LaneTrav &L) {
+    if (L.sp == 0) return kDone;
+    L.sp--;
+    return tv.stack[L.sp * kBlock];
+}
+
+// one inner-node step: test both child boxes, continue with the nearer hit child, push the other
+template <int STACK>
+__device__ __forceinline__ void trav_node_step(const TreeView &tv, LaneTrav &L) {
+    v4f a, b, c, d;
+    const int i = L.cur;
+    if (i < tv.n_lnodes) { const int S = tv.node_stride; a = tv.lnodes[i]; b = tv.lnodes[S + i]; c = tv.lnodes[2 * S + i]; d = tv.lnodes[3 * S + i]; }
+    else { a = tv.gnodes[4 * i]; b = tv.gnodes[4 * i + 1]; c = tv.gnodes[4 * i + 2]; d = tv.gnodes[4 * i + 3]; }
+    const float lo0[3] = {a.x, a.y, a.z}, hi0[3] = {b.x, b.y, b.z}, lo1[3] = {c.x, c.y, c.z}, hi1[3] = {d.x, d.y, d.z};
+    const int c0 = __float_as_int(a.w), c1 = __float_as_int(b.w);
+    float te0, te1;
+    const bool h0 = box_test(lo0, hi0, L.ray, L.ix, L.iy, L.iz, L.best.t, te0);
+    const bool h1 = box_test(lo1, hi1, L.ray, L.ix, L.iy, L.iz, L.best.t, te1);
+    if (h0 && h1) {
+        const bool near0 = te0 <= te1;
+        const int nearc = near0 ? c0 : c1, farc = near0 ? c1 : c0;
+        if (L.sp < STACK) { tv.stack[L.sp * kBlock] = farc; L.sp++; }
+        L.cur = nearc;
+    } else if (h0) L.cur = c0;
+    else if (h1) L.cur = c1;
+    else L.cur = trav_pop(tv, L);
+}
+
+// one leaf: up to 8 primitives
+__device__ __forceinline__ void trav_leaf_step(const TreeView &tv, LaneTrav &L, const bool ANY_HIT) {
+    const int code = ~L.cur;
+    const int first = code >> 3, count = (code & 7) + 1;
+    bool stop = false;
+    for (int k = 0; k < count && !stop; k++) {
+        const int pi = first + k;
+        v4f p0, p1, p2;
+        if (pi < tv.n_lprims) { const int S = tv.prim_stride; p0 = tv.lprims[pi]; p1 = tv.lprims[S + pi]; p2 = tv.lprims[2 * S + pi]; }
+        else { p0 = tv.gprims[3 * pi]; p1 = tv.gprims[3 * pi + 1]; p2 = tv.gprims[3 * pi + 2]; }
+        const int gprim = __float_as_int(p0.w), kind = __float_as_int(p1.w);
+        if (kind == 0) {
+            const float v0[3] = {p0.x, p0.y, p0.z}, v1[3] = {p1.x, p1.y, p1.z}, v2[3] = {p2.x, p2.y, p2.z};
+            float t, u, v;
+            if (tri_test(L.ray, L.best.t, v0, v1, v2, t, u, v)) {
+                if (ANY_HIT) { L.best.gprim = gprim; stop = true; }
+                else if (t < L.best.t || (t == L.best.t && (L.best.gprim < 0 || gprim < L.best.gprim))) { L.best.t = t; L.best.u = u; L.best.v = v; L.best.gprim = gprim; }
+            }
+        } else {
+            double td;
+            if (sphere_test(L.ray, tv.spheres[__float_as_int(p2.w)], td)) {
+                const float tf = (float)td;
+                if (ANY_HIT) { L.best.gprim = gprim; stop = true; }
+                else if (tf < L.best.t || (tf == L.best.t && (L.best.gprim < 0 || gprim < L.best.gprim))) { L.best.t = tf; L.best.u = 0.0f; L.best.v = 0.0f; L.best.gprim = gprim; }
+            }
         }
-        float t = 0.0f, u = 0.0f, v = 0.0f;
-        if (!(flags & PF_NO_EXT)) {  // extension ray [eps, inf) — camera rays start at 0 (camera.cpp:46, path_tracing.h:236)
-            ray.dx = q.dx[i]; ray.dy = q.dy[i]; ray.dz = q.dz[i];
-            ray.tnear = ((flags & 0xffffu) == 2u) ? 0.0f : sc.eps; ray.tfar = INFINITY;
-            HitRec h;
-            if (traverse<false>(mem, ray, h)) { code |= (h.gprim + 1); t = h.t; u = h.u; v = h.v; }
-            n_closest++;
-        }
-        q.ht[i] = t; q.hu[i] = u; q.hv[i] = v; q.hprim[i] = code;
     }
-    (void)n_closest; (void)n_shadow;
+    L.cur = stop ? kDone : trav_pop(tv, L);
+}
+
+template <int STACK>
+__global__ void __launch_bounds__(kBlock, 4) k_extend(DScene sc, DQueue q, const DBlockState *blocks, uint32_t seg, int lds_nodes, int lds_prims, uint32_t refill_min, uint32_t min_descending) {
+    const TreeView tv = stage_tree<STACK>(sc, lds_nodes, lds_prims);
+    // workgroup b traces segment b; its four waves split the live front of the segment into contiguous slices
+    const uint32_t count = blocks[blockIdx.x].count, seg_base = blockIdx.x * seg;
+    uint32_t slice = ((count + (kBlock / 64) - 1) / (kBlock / 64) + 63u) & ~63u;
+    uint32_t next = (threadIdx.x >> 6) * slice;         // wave-uniform
+    uint32_t end = next + slice; if (end > count) end = count;
+    if (next > count) next = count;
+    next += seg_base; end += seg_base;
+    // per-lane state: phase 0 = shadow ray (any hit), phase 1 = extension ray (closest hit)
+    bool busy = false; int phase = 0; uint32_t path = 0; uint32_t flags = 0; int vis = 0;
+    float edx = 0, edy = 0, edz = 0;
+    LaneTrav L; L.cur = kDone; L.sp = 0;
+    for (;;) {
+        // ---- refill: lanes without a ray take the next paths of the slice (kept wave-complete: no early exits above)
+        const unsigned long long idle = __ballot(!busy);
+        const uint32_t n_idle = (uint32_t)__popcll(idle);
+        const uint32_t left = end - next;
+        if (left > 0 && (n_idle >= refill_min || n_idle == 64u)) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+            const bool take = !busy && rank < left;
+            if (take) {
+                path = next + rank;
+                const Rec4 ro = q.ro[path], rd = q.rd[path];
+                L.ray.ox = ro.x; L.ray.oy = ro.y; L.ray.oz = ro.z;
+                edx = rd.x; edy = rd.y; edz = rd.z; flags = f2u(rd.w);
+                vis = 0; busy = true;
+                if (ro.w > 0.0f) {  // pending NEE shadow ray [eps, tfar] (path_tracing.h:124-128)
+                    const Rec4 rs = q.rs[path];
+                    L.ray.dx = rs.x; L.ray.dy = rs.y; L.ray.dz = rs.z;
+                    trav_begin(L, sc.eps, ro.w); phase = 0;
+                } else if (!(flags & PF_NO_EXT)) {  // extension ray [eps, inf); camera rays start at 0 (camera.cpp:46, path_tracing.h:236)
+                    L.ray.dx = edx; L.ray.dy = edy; L.ray.dz = edz;
+                    trav_begin(L, ((flags & 0xffffu) == 2u) ? 0.0f : sc.eps, INFINITY); phase = 1;
+                } else { q.rh[path] = mk4(0.0f, 0.0f, 0.0f, u2f(0u)); busy = false; }
+            }
+            next += n_idle < left ? n_idle : left;
+        }
+        if (__ballot(busy) == 0ull) { if (end - next == 0u) break; else continue; }
+        // ---- while-while traversal: descend inner nodes until every busy lane sits on a leaf (or is done) ...
+        // (lanes that reach a leaf wait here; once only a few lanes are still descending, everybody moves on to the
+        // leaf phase and the stragglers resume in the next round)
+        for (;;) {
+            const bool descending = busy && L.cur >= 0 && L.cur != kDone;
+            const unsigned long long dm = __ballot(descending);
+            if (dm == 0ull) break;
+            // only hand over to the leaf phase if some lane actually has a leaf to test (otherwise no progress is made)
+            if ((uint32_t)__popcll(dm) < min_descending && __ballot(busy && L.cur < 0) != 0ull) break;
+            if (descending) trav_node_step<STACK>(tv, L);
+        }
+        // ... then all of them test their leaf together
+        if (busy && L.cur < 0) trav_leaf_step(tv, L, phase == 0);
+        // ---- ray finished?
+        if (busy && L.cur == kDone) {
+            if (phase == 0) {
+                vis = (L.best.gprim < 0) ? HIT_VIS_BIT : 0;
+                if (!(flags & PF_NO_EXT)) {
+                    L.ray.dx = edx; L.ray.dy = edy; L.ray.dz = edz;
+                    trav_begin(L, sc.eps, INFINITY); phase = 1;  // a path with a pending shadow ray is never a camera ray
+                } else { q.rh[path] = mk4(0.0f, 0.0f, 0.0f, u2f((uint32_t)vis)); busy = false; }
+            } else {
+                const uint32_t code = (uint32_t)vis | (uint32_t)(L.best.gprim + 1);
+                const bool hit = L.best.gprim >= 0;
+                q.rh[path] = mk4(hit ? L.best.t : 0.0f, L.best.u, L.best.v, u2f(code));
+                busy = false;
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------- shade + compaction
@@ -131,17 +229,42 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
-__global__ void __launch_bounds__(kBlock) k_shade(DScene sc, DPass pass, DQueue qin, DQueue qout, DCtrl *c) {
-    const uint32_t n = c->n_in;
+// The shading tables every path touches in a data-dependent order (per-primitive shading records, materials, lights
+// and their cdfs) are copied to LDS once per workgroup when they fit: a chain of five or six dependent L2-latency
+// gathers per path-step becomes LDS-latency reads.  Pointers stay generic, so dshade.h is unchanged.
+struct ShadeStage { uint32_t prims_bytes, materials_bytes, lights_bytes, light_cdf_bytes, light_tris_bytes, light_tri_cdf_bytes, stage_prims; };
+
+__device__ __forceinline__ void lds_copy16(void *dst, const void *src, uint32_t bytes) {
+    const v4f *s4 = (const v4f *)src; v4f *d4 = (v4f *)dst;
+    for (uint32_t i = threadIdx.x; i < bytes / 16; i += kBlock) d4[i] = s4[i];
+}
+
+__global__ void __launch_bounds__(kBlock, 4) k_shade(DScene sc, DPass pass, DQueue q, DBlockState *blocks, uint32_t seg, ShadeStage stg) {
+    __shared__ uint32_t s_wcnt[2][kBlock / 64];
+    __shared__ unsigned long long s_cnt[5];
+    {
+        char *p = (char *)lj_smem;
+        if (stg.stage_prims) { lds_copy16(p, sc.prims, stg.prims_bytes); sc.prims = (const DPrimShade *)p; p += stg.prims_bytes; }
+        lds_copy16(p, sc.materials, stg.materials_bytes); sc.materials = (const DMaterial *)p; p += stg.materials_bytes;
+        lds_copy16(p, sc.lights, stg.lights_bytes); sc.lights = (const DLight *)p; p += stg.lights_bytes;
+        lds_copy16(p, sc.light_cdf, stg.light_cdf_bytes); sc.light_cdf = (const float *)p; p += stg.light_cdf_bytes;
+        lds_copy16(p, sc.light_tris, stg.light_tris_bytes); sc.light_tris = (const DLightTri *)p; p += stg.light_tris_bytes;
+        lds_copy16(p, sc.light_tri_cdf, stg.light_tri_cdf_bytes); sc.light_tri_cdf = (const float *)p;
+    }
+    DBlockState &bs = blocks[blockIdx.x];
+    const uint32_t count = bs.count, next_sample = bs.next_sample, end_sample = bs.end_sample;
+    if (threadIdx.x < 5) s_cnt[threadIdx.x] = 0ull;
+    __syncthreads();
     ShadeCounters cnt; cnt.bounces = cnt.closest = cnt.shadow = cnt.done = 0;
-    // every lane of a wave runs the same number of iterations so the ballots below are wave-complete
-    const uint32_t n_round = (n + 63u) & ~63u;
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_round; i += gridDim.x * kBlock) {
-        const bool active = i < n;
+    const uint32_t base = blockIdx.x * seg, wave = threadIdx.x >> 6;
+    uint32_t out = 0;  // survivors written so far (identical in every thread)
+    // ---- shade the live front of the segment chunk by chunk; survivors are compacted to the front, in order
+    for (uint32_t c0 = 0, it = 0; c0 < count; c0 += kBlock, it++) {
+        const uint32_t j = c0 + threadIdx.x;
         bool alive = false;
         PathState ps;
-        if (active) {
-            q_load_for_shade(qin, i, ps);
+        if (j < count) {
+            q_load_for_shade(q, base + j, ps);
             alive = shade_path(sc, pass, ps, cnt);
             if (!alive) {
                 float *o = pass.sample_rgb + 3ull * ps.sample;
@@ -149,22 +272,35 @@ __global__ void __launch_bounds__(kBlock) k_shade(DScene sc, DPass pass, DQueue 
                 cnt.done++;
             }
         }
-        // wave64 stream compaction of the survivors into the next queue
         const unsigned long long mask = __ballot(alive);
-        if (mask) {
-            const uint32_t lane_off = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-            uint32_t base = 0;
-            if (lane_off == 0 && alive) base = atomicAdd(&c->n_out, (uint32_t)__popcll(mask));
-            base = __shfl(base, __ffsll((long long)mask) - 1, 64);
-            if (alive) q_store(qout, base + lane_off, ps);
-        }
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        if ((threadIdx.x & 63) == 0) s_wcnt[it & 1][wave] = (uint32_t)__popcll(mask);
+        // every record of this chunk has been read (and consumed) by now, so writing into [out, out + survivors) — which
+        // never reaches past the end of this chunk — cannot overtake a read
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+        for (uint32_t w = 0; w < kBlock / 64; w++) { const uint32_t n = s_wcnt[it & 1][w]; before += (w < wave) ? n : 0u; total += n; }
+        if (alive) q_store(q, base + out + before + rank, ps);
+        out += total;
     }
-    uint32_t b = wave_sum(cnt.bounces), cl = wave_sum(cnt.closest), sh = wave_sum(cnt.shadow), dn = wave_sum(cnt.done);
+    // ---- refill the rest of the segment with the workgroup's next camera samples (path_tracing.h:10-14)
+    const uint32_t left = end_sample - next_sample, room = seg - out;
+    const uint32_t n_new = left < room ? left : room;
+    for (uint32_t g = threadIdx.x; g < n_new; g += kBlock) {
+        PathState ps;
+        generate_path(sc, pass, next_sample + g, ps);
+        q_store(q, base + out + g, ps);
+    }
+    const uint32_t b = wave_sum(cnt.bounces), cl = wave_sum(cnt.closest), sh = wave_sum(cnt.shadow), dn = wave_sum(cnt.done);
     if ((threadIdx.x & 63) == 0) {
-        if (b) atomicAdd(&c->bounce_iterations, (unsigned long long)b);
-        if (cl) atomicAdd(&c->rays_closest, (unsigned long long)cl);
-        if (sh) atomicAdd(&c->rays_shadow, (unsigned long long)sh);
-        if (dn) atomicAdd(&c->samples_done, (unsigned long long)dn);
+        atomicAdd(&s_cnt[0], (unsigned long long)b); atomicAdd(&s_cnt[1], (unsigned long long)cl); atomicAdd(&s_cnt[2], (unsigned long long)sh);
+        atomicAdd(&s_cnt[3], (unsigned long long)dn);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        bs.next_sample = next_sample + n_new;
+        bs.count = out + n_new;
+        bs.bounce_iterations += s_cnt[0]; bs.rays_closest += s_cnt[1]; bs.rays_shadow += s_cnt[2]; bs.samples_done += s_cnt[3]; bs.path_steps += count;
     }
 }
 
@@ -188,27 +324,24 @@ __global__ void __launch_bounds__(kBlock) k_resolve(DPass pass, uint32_t n_pixel
 struct RayIO { float org[3]; float tnear; float dir[3]; float tfar; };
 struct HitIO { float t, u, v; int32_t shape_id, prim_id; };
 
-template <int LDS_NODES, int LDS_PRIMS, int STACK>
-__global__ void __launch_bounds__(kBlock) k_trace_rays(DScene sc, const RayIO *rays, long long n, HitIO *hits, unsigned char *occ) {
-    __shared__ __attribute__((aligned(16))) DNode lnodes[LDS_NODES];
-    __shared__ __attribute__((aligned(16))) DPrim lprims[LDS_PRIMS];
-    __shared__ int lstack[STACK * kBlock];
-    LdsMem<LDS_NODES, LDS_PRIMS, STACK> mem;
-    stage_tree<LDS_NODES, LDS_PRIMS, STACK>(sc, lnodes, lprims, mem.n_lnodes, mem.n_lprims);
-    mem.gnodes = sc.nodes; mem.gprims = sc.leaf_prims; mem.spheres = sc.spheres;
-    mem.lnodes = lnodes; mem.lprims = lprims; mem.stack = lstack + threadIdx.x;
+template <int STACK>
+__global__ void __launch_bounds__(kBlock) k_trace_rays(DScene sc, const RayIO *rays, long long n, HitIO *hits, unsigned char *occ, int lds_nodes, int lds_prims) {
+    const TreeView tv = stage_tree<STACK>(sc, lds_nodes, lds_prims);
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
-        RayF ray;
-        ray.ox = rays[i].org[0]; ray.oy = rays[i].org[1]; ray.oz = rays[i].org[2];
-        ray.dx = rays[i].dir[0]; ray.dy = rays[i].dir[1]; ray.dz = rays[i].dir[2];
-        ray.tnear = rays[i].tnear; ray.tfar = rays[i].tfar;
-        HitRec h;
-        if (occ) { occ[i] = traverse<true>(mem, ray, h) ? 1 : 0; }
+        LaneTrav L;
+        L.ray.ox = rays[i].org[0]; L.ray.oy = rays[i].org[1]; L.ray.oz = rays[i].org[2];
+        L.ray.dx = rays[i].dir[0]; L.ray.dy = rays[i].dir[1]; L.ray.dz = rays[i].dir[2];
+        trav_begin(L, rays[i].tnear, rays[i].tfar);
+        while (L.cur != kDone) {
+            while (L.cur >= 0 && L.cur != kDone) trav_node_step<STACK>(tv, L);
+            if (L.cur < 0) trav_leaf_step(tv, L, occ != nullptr);
+        }
+        if (occ) occ[i] = L.best.gprim >= 0 ? 1 : 0;
         else {
             HitIO o; o.t = 0; o.u = 0; o.v = 0; o.shape_id = -1; o.prim_id = -1;
-            if (traverse<false>(mem, ray, h)) {
-                const DPrimShade &ps = sc.prims[h.gprim];
-                o.t = h.t; o.u = h.u; o.v = h.v; o.shape_id = ps.shape_id; o.prim_id = ps.prim_id;
+            if (L.best.gprim >= 0) {
+                const DPrimShade &ps = sc.prims[L.best.gprim];
+                o.t = L.best.t; o.u = L.best.u; o.v = L.best.v; o.shape_id = ps.shape_id; o.prim_id = ps.prim_id;
             }
             hits[i] = o;
         }
@@ -216,32 +349,63 @@ __global__ void __launch_bounds__(kBlock) k_trace_rays(DScene sc, const RayIO *r
 }
 
 // ---------------------------------------------------------------- launchers (called from api_device.hip)
-// Small scenes: the whole BVH and all primitives sit in LDS (cbox: 38 triangles).  Large scenes: the top of the tree.
-constexpr int kSmallNodes = 128, kSmallPrims = 256, kSmallStack = 16;
-constexpr int kLargeNodes = 384, kLargePrims = 1, kLargeStack = 40;
+// Two stack depths are compiled: 16 levels cover every small scene, 40 the deepest BVH the builder may emit.
+// LDS per 256-thread workgroup = STACK * 1 KiB + staged nodes * 64 B + staged prims * 48 B.
+struct ExtendConfig { int stack; int lds_nodes; int lds_prims; size_t smem; uint32_t refill_min, min_descending; };
 
-bool scene_is_small(int n_nodes, int n_prims, int bvh_depth) { return n_nodes <= kSmallNodes && n_prims <= kSmallPrims && bvh_depth <= kSmallStack; }
-int large_stack_depth() { return kLargeStack; }
+ExtendConfig extend_config(int n_nodes, int n_prims, int bvh_depth) {
+    ExtendConfig c;
+    if (bvh_depth <= 16) {
+        c.stack = 16;
+        c.lds_nodes = n_nodes < 256 ? n_nodes : 256;       // <= 16 KiB of nodes
+        c.lds_prims = n_prims <= 256 ? n_prims : 0;        // primitives only when the whole scene fits (<= 12 KiB)
+    } else {
+        c.stack = 40;
+        c.lds_nodes = n_nodes < 256 ? n_nodes : 256;
+        c.lds_prims = 0;
+    }
+    c.smem = (size_t)c.stack * kBlock * 4 + (size_t)c.lds_nodes * 64 + (size_t)c.lds_prims * 48;
+    c.refill_min = 8; c.min_descending = 1;  // tuned on cbox / MI355X (tools/tune.sh)
+    return c;
+}
+int max_stack_depth() { return 40; }
 
-void launch_prepare(DCtrl *c, hipStream_t s) { hipLaunchKernelGGL(k_prepare, dim3(1), dim3(1), 0, s, c); }
-void launch_generate(const DScene &sc, const DPass &pass, const DQueue &q, const DCtrl *c, int grid, hipStream_t s) {
-    hipLaunchKernelGGL(k_generate, dim3(grid), dim3(kBlock), 0, s, sc, pass, q, c);
+// LDS staging plan of the shade kernel; sizes are rounded up to 16 bytes (the device buffers are padded accordingly).
+struct ShadeConfig { uint32_t prims_bytes, materials_bytes, lights_bytes, light_cdf_bytes, light_tris_bytes, light_tri_cdf_bytes, stage_prims; size_t smem; };
+ShadeConfig shade_config(size_t n_prims, size_t n_materials, size_t n_lights, size_t n_light_tris, size_t n_light_tri_cdf) {
+    auto r16 = [](size_t b) { return (uint32_t)((b + 15) & ~(size_t)15); };
+    ShadeConfig c{};
+    c.materials_bytes = r16(n_materials * sizeof(DMaterial)); c.lights_bytes = r16(n_lights * sizeof(DLight));
+    c.light_cdf_bytes = r16((n_lights + 1) * 4); c.light_tris_bytes = r16(n_light_tris * sizeof(DLightTri)); c.light_tri_cdf_bytes = r16(n_light_tri_cdf * 4);
+    size_t small = (size_t)c.materials_bytes + c.lights_bytes + c.light_cdf_bytes + c.light_tris_bytes + c.light_tri_cdf_bytes;
+    if (small > 24 * 1024) {  // too many materials / emissive triangles: leave everything in global memory
+        c = ShadeConfig{}; c.smem = 0; return c;
+    }
+    c.prims_bytes = r16(n_prims * sizeof(DPrimShade));
+    c.stage_prims = (small + c.prims_bytes <= 32 * 1024) ? 1u : 0u;
+    if (!c.stage_prims) c.prims_bytes = 0;
+    c.smem = small + c.prims_bytes;
+    return c;
 }
-void launch_extend(const DScene &sc, const DQueue &q, DCtrl *c, bool small, int grid, hipStream_t s) {
-    if (small) hipLaunchKernelGGL((k_extend<kSmallNodes, kSmallPrims, kSmallStack>), dim3(grid), dim3(kBlock), 0, s, sc, q, c);
-    else hipLaunchKernelGGL((k_extend<kLargeNodes, kLargePrims, kLargeStack>), dim3(grid), dim3(kBlock), 0, s, sc, q, c);
+
+void launch_extend(const DScene &sc, const DQueue &q, const DBlockState *blocks, uint32_t n_blocks, uint32_t seg, const ExtendConfig &cfg, hipStream_t s) {
+    if (cfg.stack == 16) hipLaunchKernelGGL((k_extend<16>), dim3(n_blocks), dim3(kBlock), cfg.smem, s, sc, q, blocks, seg, cfg.lds_nodes, cfg.lds_prims, cfg.refill_min, cfg.min_descending);
+    else hipLaunchKernelGGL((k_extend<40>), dim3(n_blocks), dim3(kBlock), cfg.smem, s, sc, q, blocks, seg, cfg.lds_nodes, cfg.lds_prims, cfg.refill_min, cfg.min_descending);
 }
-void launch_shade(const DScene &sc, const DPass &pass, const DQueue &qin, const DQueue &qout, DCtrl *c, int grid, hipStream_t s) {
-    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kBlock), 0, s, sc, pass, qin, qout, c);
+void launch_shade(const DScene &sc, const DPass &pass, const DQueue &q, DBlockState *blocks, uint32_t n_blocks, uint32_t seg, const ShadeConfig &cfg, hipStream_t s) {
+    ShadeStage st;
+    st.prims_bytes = cfg.prims_bytes; st.materials_bytes = cfg.materials_bytes; st.lights_bytes = cfg.lights_bytes; st.light_cdf_bytes = cfg.light_cdf_bytes;
+    st.light_tris_bytes = cfg.light_tris_bytes; st.light_tri_cdf_bytes = cfg.light_tri_cdf_bytes; st.stage_prims = cfg.stage_prims;
+    hipLaunchKernelGGL(k_shade, dim3(n_blocks), dim3(kBlock), cfg.smem, s, sc, pass, q, blocks, seg, st);
 }
 void launch_resolve(const DPass &pass, uint32_t n_pixels, float *rgb, hipStream_t s) {
     const uint32_t waves_per_block = kBlock / 64;
     const uint32_t grid = (n_pixels + waves_per_block - 1) / waves_per_block;
     if (grid) hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(kBlock), 0, s, pass, n_pixels, rgb);
 }
-void launch_trace_rays(const DScene &sc, const void *rays, long long n, void *hits, unsigned char *occ, bool small, int grid, hipStream_t s) {
-    if (small) hipLaunchKernelGGL((k_trace_rays<kSmallNodes, kSmallPrims, kSmallStack>), dim3(grid), dim3(kBlock), 0, s, sc, (const RayIO *)rays, n, (HitIO *)hits, occ);
-    else hipLaunchKernelGGL((k_trace_rays<kLargeNodes, kLargePrims, kLargeStack>), dim3(grid), dim3(kBlock), 0, s, sc, (const RayIO *)rays, n, (HitIO *)hits, occ);
+void launch_trace_rays(const DScene &sc, const void *rays, long long n, void *hits, unsigned char *occ, const ExtendConfig &cfg, int grid, hipStream_t s) {
+    if (cfg.stack == 16) hipLaunchKernelGGL((k_trace_rays<16>), dim3(grid), dim3(kBlock), cfg.smem, s, sc, (const RayIO *)rays, n, (HitIO *)hits, occ, cfg.lds_nodes, cfg.lds_prims);
+    else hipLaunchKernelGGL((k_trace_rays<40>), dim3(grid), dim3(kBlock), cfg.smem, s, sc, (const RayIO *)rays, n, (HitIO *)hits, occ, cfg.lds_nodes, cfg.lds_prims);
 }
 
 } // namespace ljd

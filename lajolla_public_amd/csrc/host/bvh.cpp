@@ -48,7 +48,7 @@ struct Builder {
         }
         tmp[id].box = box; tmp[id].depth = depth;
         auto make_leaf = [&]() { tmp[id].first = first; tmp[id].count = count; return id; };
-        if (count <= 1 || depth >= max_depth) return make_leaf();
+        if (count <= 1 || (depth >= max_depth && count <= 8)) return make_leaf();
         // binned SAH over the three axes
         constexpr int kBins = 16;
         float best_cost = std::numeric_limits<float>::infinity(); int best_axis = -1, best_bin = -1;
@@ -115,7 +115,9 @@ void build_bvh(const std::vector<BuildPrim> &prims, int max_leaf, int max_depth,
     for (int i = 0; i < n; i++) { b.order[i] = i; for (int k = 0; k < 3; k++) b.centroid[3 * i + k] = 0.5f * (prims[i].lo[k] + prims[i].hi[k]); }
     b.tmp.reserve(2 * (size_t)n);
     int root = b.build(0, n, 0);
-    // A leaf that ended up larger than max_leaf because of the depth cap stays as it is: correctness first.
+    // Leaves hold at most 8 primitives (3-bit count in the child code); beyond the depth cap the builder keeps
+    // splitting until that holds, and the caller checks the resulting depth against its traversal stack.
+    if ((long long)n * 8 >= (1ll << 30)) throw LjError(LJ_ERR_UNSUPPORTED, "too many primitives for the 30-bit leaf code");
     leaf_order = b.order;
     // breadth-first numbering of the inner nodes; leaves are folded into their parent's record
     std::vector<int> bfs;  // TmpNode ids of inner nodes in output order
@@ -124,7 +126,7 @@ void build_bvh(const std::vector<BuildPrim> &prims, int max_leaf, int max_depth,
     if (is_leaf(root)) {
         ljd::DNode nd{};
         memcpy(nd.lo0, b.tmp[root].box.lo, 12); memcpy(nd.hi0, b.tmp[root].box.hi, 12);
-        nd.c0 = ~b.tmp[root].first; nd.n0 = b.tmp[root].count;
+        nd.c0 = ~(b.tmp[root].first * 8 + b.tmp[root].count - 1); nd.n0 = b.tmp[root].count;
         empty_child(nd.lo1, nd.hi1); nd.c1 = -1; nd.n1 = 0;
         nodes.push_back(nd); depth_out = 1;
         return;
@@ -141,8 +143,8 @@ void build_bvh(const std::vector<BuildPrim> &prims, int max_leaf, int max_depth,
         const TmpNode &L = b.tmp[t.left], &R = b.tmp[t.right];
         memcpy(nd.lo0, L.box.lo, 12); memcpy(nd.hi0, L.box.hi, 12);
         memcpy(nd.lo1, R.box.lo, 12); memcpy(nd.hi1, R.box.hi, 12);
-        if (is_leaf(t.left)) { nd.c0 = ~L.first; nd.n0 = L.count; } else { nd.c0 = out_index[t.left]; nd.n0 = 0; }
-        if (is_leaf(t.right)) { nd.c1 = ~R.first; nd.n1 = R.count; } else { nd.c1 = out_index[t.right]; nd.n1 = 0; }
+        if (is_leaf(t.left)) { nd.c0 = ~(L.first * 8 + L.count - 1); nd.n0 = L.count; } else { nd.c0 = out_index[t.left]; nd.n0 = 0; }
+        if (is_leaf(t.right)) { nd.c1 = ~(R.first * 8 + R.count - 1); nd.n1 = R.count; } else { nd.c1 = out_index[t.right]; nd.n1 = 0; }
         nodes[h] = nd;
         depth_out = std::max(depth_out, t.depth + 1);
     }

@@ -1,0 +1,104 @@
+"""CPU-side checks of the product library: it loads, exports every symbol include/lajolla_hip.h declares, the ctypes
+mirror matches the C struct sizes, device entry points fail loudly without a GPU, and the host flattening (bounds,
+tables, BVH) reproduces the reference's Scene::Scene numbers."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import lajolla_public_amd as lj
+from lajolla_public_amd import _abi
+from helpers import ROOT, Oracle, Twin, golden, random_rays, scene_path
+
+
+def _has_gpu():
+    import torch
+    return torch.cuda.is_available()
+
+
+def test_library_exports_every_declared_symbol():
+    lib = lj.load_library()
+    header = open(os.path.join(ROOT, "include", "lajolla_hip.h")).read()
+    declared = set(re.findall(r"\b(lj_[a-z_0-9]+)\s*\(", header))
+    assert declared == {name for name, _, _ in _abi.SYMBOLS}, "ctypes SYMBOLS table out of sync with the header"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert b"gfx950" in lib.lj_version()
+
+
+def test_struct_sizes_match_the_header(tmp_path):
+    """Compile a tiny C program against the header and compare sizeof() with the ctypes mirror."""
+    names = ["LjTexture", "LjMaterial", "LjShape", "LjLight", "LjImage", "LjCamera", "LjRenderOptions", "LjSceneDesc", "LjRenderArgs",
+             "LjRay", "LjHit", "LjStats", "LjSceneInfo"]
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "lajolla_hip.h"\nint main(){' + "".join(f'printf("%zu\\n", sizeof({n}));' for n in names) + "return 0;}")
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])  # the header is plain C
+    sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    for n, s in zip(names, sizes):
+        assert C.sizeof(getattr(_abi, n)) == s, n
+
+
+@pytest.mark.skipif(_has_gpu(), reason="checks the no-GPU failure mode")
+def test_device_entry_points_fail_loudly_without_a_gpu():
+    with pytest.raises(lj.LajollaError) as e:
+        lj.Context(0)
+    assert e.value.code == _abi.LJ_ERR_DEVICE and "no CPU path" in str(e.value)
+
+
+def test_null_arguments_are_rejected():
+    lib = lj.load_library()
+    assert lib.lj_parse_scene(None, None) == _abi.LJ_ERR_INVALID_ARG
+    assert lib.lj_scene_upload(None, None, None) == _abi.LJ_ERR_INVALID_ARG
+    assert lib.lj_render(None, None, None) == _abi.LJ_ERR_INVALID_ARG
+    assert lib.lj_get_stats(None, None) == _abi.LJ_ERR_INVALID_ARG
+    assert b"null" in lib.lj_last_error()
+
+
+@pytest.mark.parametrize("name", ["cbox", "veach_mi"])
+def test_flattened_tables_match_reference(name):
+    """The host half of Scene::Scene (scene.cpp:30-52) as the product computes it, against the reference's numbers."""
+    hs = lj.parse_scene(scene_path(name))
+    g = golden("scene_" + name)
+    t = Twin(hs).tables()
+    assert np.isclose(t["bounds_radius"], g["bounds_radius"], rtol=1e-12) and np.allclose(t["bounds_center"], g["bounds_center"], rtol=1e-12)
+    assert np.isclose(t["shadow_epsilon"], g["shadow_epsilon"], rtol=1e-12)
+    assert np.allclose(t["light_pmf"], g["light_pmf"], rtol=1e-12) and np.allclose(t["light_cdf"], g["light_cdf"], rtol=1e-12)
+    assert np.allclose(t["light_power"], [l["power"] for l in g["lights"]], rtol=1e-12)
+    assert t["bvh_depth"] <= 16 and t["n_nodes"] >= 1
+
+
+@pytest.mark.parametrize("name", ["cbox", "veach_mi"])
+def test_bvh_traversal_equals_brute_force(name):
+    """The device traversal code (host build) over the SAH BVH must return bit-identical hits to the oracle's
+    exhaustive scan: closest hit = min (t, primitive id), so the result cannot depend on the tree."""
+    hs = lj.parse_scene(scene_path(name))
+    o = Oracle(hs)
+    tw = Twin(hs)
+    rays = random_rays(hs, 100000, 7, o)
+    ho, ht = o.intersect(rays), tw.intersect(rays)
+    assert (ho["shape_id"] >= 0).mean() > 0.3
+    for f in ("t", "u", "v", "shape_id", "prim_id"):
+        assert np.array_equal(ho[f].view(np.uint32), ht[f].view(np.uint32)), f
+    # bounded segments: any-hit
+    rays2 = rays.copy()
+    rays2["tnear"] = 1e-3
+    rays2["tfar"] = np.random.default_rng(3).random(len(rays)).astype(np.float32) * o.tables()["bounds_radius"]
+    assert np.array_equal(o.occluded(rays2), tw.occluded(rays2))
+    # and the oracle's own median-split BVH agrees with its brute force
+    o.use_bvh(True)
+    hb = o.intersect(rays)
+    for f in ("t", "u", "v", "shape_id", "prim_id"):
+        assert np.array_equal(ho[f].view(np.uint32), hb[f].view(np.uint32)), f
+
+
+def test_unsupported_variants_fail_loudly():
+    """A material alternative the device path does not implement must raise LJ_ERR_UNSUPPORTED, never fall back."""
+    hs = lj.parse_scene(scene_path("cbox"))
+    hs.desc.materials[0].kind = _abi.LJ_MAT_DISNEYBSDF if hasattr(_abi, "LJ_MAT_DISNEYBSDF") else 8
+    with pytest.raises(RuntimeError) as e:
+        Twin(hs)
+    assert "not implemented" in str(e.value)

@@ -1,0 +1,255 @@
+"""Pins the CPU oracle (oracle/lj_oracle.cpp) to the reference: every value here was produced by the reference's own
+functions, compiled from /root/reference by oracle/ref_build.sh and recorded by oracle/gen_golden.cpp.
+Tolerance: 1e-12 relative (same double arithmetic, possibly different association) unless stated; integers exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import lajolla_public_amd as lj
+from lajolla_public_amd import _abi
+from helpers import Oracle, darr, dptr, golden, oracle_lib, scene_path
+
+REL = 1e-12
+
+
+def close(a, b, rel=REL, abs_=1e-300):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return np.all(np.abs(a - b) <= rel * np.maximum(np.abs(a), np.abs(b)) + abs_)
+
+
+@pytest.fixture(scope="module")
+def core():
+    return golden("core")
+
+
+def test_pcg32_known_answers(core):
+    lib = oracle_lib()
+    for g in core["pcg32"]:
+        u32 = np.zeros(16, np.uint32)
+        f64 = np.zeros(8)
+        f32 = np.zeros(8, np.float32)
+        st, inc = C.c_uint64(), C.c_uint64()
+        lib.oracle_pcg32(C.c_uint64(int(g["stream"])), C.c_uint64(0), 16, u32.ctypes.data_as(C.c_void_p), 8, dptr(f64), 8,
+                         f32.ctypes.data_as(C.c_void_p), C.byref(st), C.byref(inc))
+        assert st.value == int(g["state0"]) and inc.value == int(g["inc"])
+        assert u32.tolist() == g["u32"]
+        assert f64.tolist() == g["f64"]          # bit-exact: integer construction of the mantissa (pcg.h:61-68)
+        assert f32.astype(float).tolist() == g["f32"]
+
+
+def test_filters(core):
+    lib = oracle_lib()
+    kinds = {"box": 0, "tent": 1, "gaussian": 2}
+    for g in core["filters"]:
+        out = np.zeros(2)
+        lib.oracle_filter_sample(kinds[g["kind"]], C.c_double(g["param"]), dptr(darr(g["rnd"])), dptr(out))
+        assert close(out, g["out"]), g
+
+
+def test_frames(core):
+    lib = oracle_lib()
+    for g in core["frames"]:
+        x, y, tl, tw = (np.zeros(3) for _ in range(4))
+        lib.oracle_frame(dptr(darr(g["n"])), dptr(darr(g["v"])), dptr(x), dptr(y), dptr(tl), dptr(tw))
+        assert close(x, g["x"]) and close(y, g["y"]) and close(tl, g["to_local"], abs_=1e-15) and close(tw, g["to_world"], abs_=1e-15)
+
+
+def test_ray_differentials(core):
+    lib = oracle_lib()
+    for g in core["raydiff"]:
+        out = np.zeros(3)
+        lib.oracle_raydiff(C.c_double(g["radius"]), C.c_double(g["spread"]), C.c_double(g["dist"]), C.c_double(g["curv"]),
+                           C.c_double(g["rough"]), C.c_double(g["eta"]), dptr(out))
+        assert close(out, [g["transfer"], g["reflect"], g["refract"]])
+
+
+def test_table_dist_1d(core):
+    lib = oracle_lib()
+    g = core["table1d"]
+    n = len(g["f"])
+    pmf, cdf = np.zeros(n), np.zeros(n + 1)
+    us = darr([s["u"] for s in g["samples"]])
+    ids = np.zeros(len(us), np.int32)
+    lib.oracle_table1d(n, dptr(darr(g["f"])), dptr(pmf), dptr(cdf), len(us), dptr(us), ids.ctypes.data_as(C.c_void_p))
+    assert close(pmf, g["pmf"]) and close(cdf, g["cdf"])
+    assert cdf[-1] == pytest.approx(sum(g["f"]))  # the last entry stays un-normalised (table_dist.cpp:13-17)
+    assert ids.tolist() == [s["id"] for s in g["samples"]]
+
+
+def test_table_dist_2d(core):
+    lib = oracle_lib()
+    g = core["table2d"]
+    w, h = g["width"], g["height"]
+    cr, pr, cm, pm = np.zeros(h * (w + 1)), np.zeros(h * w), np.zeros(h + 1), np.zeros(h)
+    tot = C.c_double()
+    rnd = darr([s["rnd"] for s in g["samples"]])
+    xy, pdfs = np.zeros((len(rnd), 2)), np.zeros(len(rnd))
+    lib.oracle_table2d(w, h, dptr(darr(g["f"])), dptr(cr), dptr(pr), dptr(cm), dptr(pm), C.byref(tot), len(rnd), dptr(rnd), dptr(xy), dptr(pdfs))
+    assert close(cr, g["cdf_rows"]) and close(pr, g["pdf_rows"]) and close(cm, g["cdf_marginals"]) and close(pm, g["pdf_marginals"])
+    assert close(tot.value, g["total_values"])
+    assert close(xy, [s["xy"] for s in g["samples"]]) and close(pdfs, [s["pdf"] for s in g["samples"]])
+
+
+# ---------------------------------------------------------------- scene-level fixtures
+SCENES = ["cbox", "veach_mi"]
+
+
+@pytest.fixture(scope="module", params=SCENES)
+def scene(request):
+    hs = lj.parse_scene(scene_path(request.param))
+    return request.param, hs, Oracle(hs), golden("scene_" + request.param)
+
+
+def test_scene_tables(scene):
+    name, hs, o, g = scene
+    t = o.tables()
+    assert close(t["bounds_radius"], g["bounds_radius"]) and close(t["bounds_center"], g["bounds_center"])
+    assert close(t["shadow_epsilon"], g["shadow_epsilon"])
+    assert close(t["light_pmf"], g["light_pmf"]) and close(t["light_cdf"], g["light_cdf"])
+    assert close(t["light_power"], [l["power"] for l in g["lights"]])
+    lib = oracle_lib()
+    for sid, s in enumerate(g["shapes"]):
+        if s["kind"] != "trimesh":
+            continue
+        assert close(lib.oracle_mesh_total_area(o.h, sid), s["total_area"])
+        if "tri_cdf" in s:
+            n = s["n_indices"]
+            pmf, cdf = np.zeros(n), np.zeros(n + 1)
+            assert lib.oracle_mesh_tri_cdf(o.h, sid, dptr(pmf), dptr(cdf)) == n
+            assert close(pmf, s["tri_pmf"]) and close(cdf, s["tri_cdf"])
+
+
+def test_primary_rays(scene):
+    name, hs, o, g = scene
+    org, d = o.sample_primary([p["screen_pos"] for p in g["primary"]])
+    assert close(org, [p["org"] for p in g["primary"]]) and close(d, [p["dir"] for p in g["primary"]], abs_=1e-15)
+
+
+def test_light_selection(scene):
+    name, hs, o, g = scene
+    for s in g["sample_light"]:
+        assert o.sample_light(s["u"]) == s["id"]
+
+
+def test_light_sampling_pdf_emission(scene):
+    name, hs, o, g = scene
+    for s in g["light_samples"]:
+        pos, nrm, pdf, em = o.light_sample(s["light_id"], s["ref"], s["uv"], s["w"], s["view_dir"], s["footprint"])
+        assert close(pos, s["position"], rel=1e-11, abs_=1e-12), s
+        assert close(nrm, s["normal"], rel=1e-11, abs_=1e-12), s
+        assert close(pdf, s["pdf"], rel=1e-9), s   # sphere cone pdf: 1 - cos_max cancellation amplifies last-bit differences
+        assert close(em, s["emission"]), s
+
+
+def _material_struct(m):
+    """golden material dict -> LjMaterial"""
+    out = _abi.LjMaterial()
+    out.kind = _abi.MATERIAL_KINDS.index(m["kind"])
+    slots = _abi.MATERIAL_SLOTS[m["kind"]]
+    out.n_tex = len(slots)
+    out.eta = m.get("eta", 0.0)
+    tk = {"constant": 0, "image": 1, "checkerboard": 2}
+    for i, sname in enumerate(slots):
+        t = m[sname]
+        tex = out.tex[i]
+        tex.kind = tk[t["kind"]]
+        tex.texture_id = t.get("texture_id", -1)
+        v = t.get("value", t.get("color0", 0.0))
+        v = [v] * 3 if not isinstance(v, list) else v
+        c1 = t.get("color1", 0.0)
+        c1 = [c1] * 3 if not isinstance(c1, list) else c1
+        for k in range(3):
+            tex.value[k], tex.color1[k] = v[k], c1[k]
+        tex.uscale, tex.vscale = t.get("uscale", 1.0), t.get("vscale", 1.0)
+        tex.uoffset, tex.voffset = t.get("uoffset", 0.0), t.get("voffset", 0.0)
+    return out
+
+
+def _vertex22(v):
+    return np.array(v["position"] + v["geometry_normal"] + v["frame_x"] + v["frame_y"] + v["frame_n"] + v["st"] + v["uv"] +
+                    [v["uv_screen_size"], v["mean_curvature"], v["ray_radius"]], float)
+
+
+def test_path_vertices_and_bsdf_at_vertices(scene):
+    """compute_shading_info + the PathVertex assembly of intersect() (intersection.cpp:38-62), then the BSDF there."""
+    name, hs, o, g = scene
+    for rec in g["vertices"]:
+        v = rec["vertex"]
+        out, mid, em = o.make_vertex(rec["ray_org"], rec["ray_dir"], rec["rd_radius"], rec["rd_spread"], v["shape_id"], v["primitive_id"],
+                                     rec["t"], rec["u"], rec["v"], rec["Ng"])
+        assert mid == v["material_id"]
+        assert close(out, _vertex22(v), rel=1e-11, abs_=1e-13), (name, v["shape_id"], v["primitive_id"])
+        if "emission" in rec:
+            assert close(em, rec["emission"])
+        mat = hs.desc.materials[mid]
+        for b in rec.get("bsdf", []):
+            rc, ev, pdf, valid, sd, eta, rough = o.bsdf(mat, out, b["dir_in"], b["dir_out"], b["rnd_uv"], b["rnd_w"])
+            assert rc == 0
+            assert close(ev, b["eval"], rel=1e-10, abs_=1e-15) and close(pdf, b["pdf"], rel=1e-10, abs_=1e-15)
+            assert valid == b["sample_valid"]
+            if valid:
+                assert close(sd, b["sample_dir"], rel=1e-10, abs_=1e-13) and eta == b["sample_eta"] and close(rough, b["sample_roughness"])
+
+
+def test_material_kats():
+    """eval / pdf_sample_bsdf / sample_bsdf for the material alternatives the oracle restates so far."""
+    g = golden("materials")
+    hs = lj.parse_scene(scene_path("cbox"))
+    o = Oracle(hs)
+    done, todo = {}, {}
+    for case in g["cases"]:
+        kind = case["material"]["kind"]
+        mat = _material_struct(case["material"])
+        vx = np.array([0, 0, 0] + case["geometry_normal"] + case["frame_x"] + case["frame_y"] + case["frame_n"] + [0, 0] + case["uv"] +
+                      [case["uv_screen_size"], 0, 0], float)
+        for q in case["queries"]:
+            if q["to_view"]:
+                continue
+            rc, ev, pdf, valid, sd, eta, rough = o.bsdf(mat, vx, case["dir_in"], q["dir_out"], q["rnd_uv"], q["rnd_w"])
+            if rc != 0:
+                todo[kind] = todo.get(kind, 0) + 1
+                continue
+            done[kind] = done.get(kind, 0) + 1
+            assert close(ev, q["eval"], rel=1e-10, abs_=1e-15), (kind, q)
+            assert close(pdf, q["pdf"], rel=1e-10, abs_=1e-15), (kind, q)
+            assert valid == q["sample_valid"], (kind, q)
+            if valid:
+                assert close(sd, q["sample_dir"], rel=1e-10, abs_=1e-13) and close(eta, q["sample_eta"]) and close(rough, q["sample_roughness"])
+    assert done.get("lambertian", 0) >= 200 and done.get("roughplastic", 0) >= 200
+    # kinds not yet restated are reported, not silently passed
+    print("material KATs checked:", done, "not restated yet:", todo)
+
+
+def test_reference_intersection_fixture():
+    """src/tests/intersection.cpp:4-42 re-expressed: one triangle at z=-1, a ray from the origin along -z must hit at
+    (0,0,-1) within 1e-3.  This is the only fixture the reference holds for the Embree-backed path."""
+    d = _abi.LjSceneDesc()
+    cam = d.camera
+    ident = [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1]
+    for i in range(16):
+        cam.cam_to_world[i] = cam.world_to_cam[i] = cam.sample_to_cam[i] = cam.cam_to_sample[i] = ident[i]
+    cam.width = cam.height = 1
+    pos = darr([[-1, -1, -1], [1, -1, -1], [0, 1, -1]])
+    idx = np.array([[0, 1, 2]], np.int32)
+    nrm, uvs = np.zeros((3, 3)), np.zeros((3, 2))
+    shape = _abi.LjShape()
+    shape.kind = _abi.LJ_SHAPE_TRIMESH
+    shape.material_id, shape.area_light_id = 0, -1
+    shape.n_vertices, shape.n_triangles = 3, 1
+    mat = _abi.LjMaterial()
+    mat.kind, mat.n_tex = 0, 1
+    d.n_shapes, d.n_materials = 1, 1
+    d.shapes, d.materials = C.pointer(shape), C.pointer(mat)
+    d.n_vertices, d.n_triangles = 3, 1
+    d.positions, d.normals, d.uvs = dptr(pos), dptr(nrm), dptr(uvs)
+    d.indices = idx.ctypes.data_as(C.POINTER(C.c_int32))
+    d.envmap_light_id = -1
+    lib = oracle_lib()
+    h = C.c_void_p(lib.oracle_scene_create(C.byref(d)))
+    out = np.zeros(22)
+    sid, pid = C.c_int(), C.c_int()
+    hit = lib.oracle_intersect_vertex(h, dptr(darr([0, 0, 0])), dptr(darr([0, 0, -1])), C.c_double(0), C.c_double(np.inf), dptr(out), C.byref(sid), C.byref(pid))
+    assert hit == 1 and sid.value == 0 and pid.value == 0
+    assert np.linalg.norm(out[:3] - np.array([0, 0, -1])) < 1e-3
+    lib.oracle_scene_free(h)
