@@ -7,6 +7,8 @@
 #include "../../lajolla_public_amd/csrc/device/dshade.h"
 #include "../../lajolla_public_amd/csrc/device/dtrace.h"
 #include "../../lajolla_public_amd/csrc/host/flatten.h"
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -18,14 +20,18 @@ namespace {
 struct HostMem {
     const DScene &sc;
     int stack[64];
+    mutable unsigned long long n_nodes = 0, n_prims = 0;
     explicit HostMem(const DScene &s) : sc(s) {}
-    DNode node(int i) const { return sc.nodes[i]; }
-    DPrim prim(int i) const { return sc.leaf_prims[i]; }
+    DNode node(int i) const { n_nodes++; return sc.nodes[i]; }
+    DPrim prim(int i) const { n_prims++; return sc.leaf_prims[i]; }
     const DSphere &sphere(int s) const { return sc.spheres[s]; }
     void push(int sp, int v) { stack[sp] = v; }
     int pop(int sp) const { return stack[sp]; }
     int max_stack() const { return 64; }
 };
+
+// traversal work counters (debugging aid): [shadow rays, shadow nodes, shadow prims, ext rays, ext nodes, ext prims]
+static thread_local unsigned long long g_trav[6];
 
 // what k_extend does for one queue slot
 void extend_one(const DScene &sc, PathState &ps) {
@@ -36,6 +42,7 @@ void extend_one(const DScene &sc, PathState &ps) {
         ray.dx = ps.sdir.x; ray.dy = ps.sdir.y; ray.dz = ps.sdir.z; ray.tnear = sc.eps; ray.tfar = ps.stfar;
         HitRec h;
         if (!traverse<true>(mem, ray, h)) code |= HIT_VIS_BIT;
+        g_trav[0]++; g_trav[1] += mem.n_nodes; g_trav[2] += mem.n_prims; mem.n_nodes = mem.n_prims = 0;
     }
     float t = 0, u = 0, v = 0;
     if (!(ps.flags & PF_NO_EXT)) {
@@ -43,6 +50,7 @@ void extend_one(const DScene &sc, PathState &ps) {
         ray.tnear = ((ps.flags & 0xffffu) == 2u) ? 0.0f : sc.eps; ray.tfar = INFINITY;
         HitRec h;
         if (traverse<false>(mem, ray, h)) { code |= (h.gprim + 1); t = h.t; u = h.u; v = h.v; }
+        g_trav[3]++; g_trav[4] += mem.n_nodes; g_trav[5] += mem.n_prims;
     }
     ps.ht = t; ps.hu = u; ps.hv = v; ps.hcode = code;
 }
@@ -102,6 +110,7 @@ void twin_render_samples(void *tv, int spp, int max_depth, int use_max_depth, ui
             out[3 * s] = ps.rad.x; out[3 * s + 1] = ps.rad.y; out[3 * s + 2] = ps.rad.z;
         }
         bounces[tid] = cnt.bounces;
+        if (getenv("LJ_TWIN_TRAV")) fprintf(stderr, "trav[%d]: shadow rays %llu nodes/ray %.2f prims/ray %.2f | ext rays %llu nodes/ray %.2f prims/ray %.2f\n", tid, g_trav[0], g_trav[1] / (double)g_trav[0], g_trav[2] / (double)g_trav[0], g_trav[3], g_trav[4] / (double)g_trav[3], g_trav[5] / (double)g_trav[3]);
     };
     std::vector<std::thread> th;
     for (int i = 1; i < n_threads; i++) th.emplace_back(worker, i);
