@@ -277,19 +277,243 @@ LJ_HD f3 sample_visible_normals(f3 local_dir_in, float alpha, float r0, float r1
     return flipped ? -n : n;
 }
 
-struct BsdfSample { f3 dir_out; float eta, roughness; bool valid; };
 
 LJ_HD f3 tex3(const DScene &sc, const DMaterial &m, int slot, const DVertex &vx) { return eval_texture(sc, m.tex[slot], true, vx.u, vx.v, vx.uv_screen_size); }
 LJ_HD float tex1(const DScene &sc, const DMaterial &m, int slot, const DVertex &vx) { return eval_texture(sc, m.tex[slot], false, vx.u, vx.v, vx.uv_screen_size).x; }
+
+// ---- Disney family helpers (disney_metal.inl:3-50, disney_clearcoat.inl:3-16); pow(x, 5) / pow(x, 2) spelled as products
+LJ_HD float pow5(float x) { float x2 = x * x; return x2 * x2 * x; }
+LJ_HD float sqr(float x) { return x * x; }
+LJ_HD float smithG_GGX_aniso(float NdotW, float WdotX, float WdotY, float ax, float ay) {
+    float lambda = 0.5f * (sqrtf(1.0f + (sqr(WdotX * ax) + sqr(WdotY * ay)) / sqr(NdotW)) - 1.0f);
+    return 1.0f / (1.0f + lambda);
+}
+LJ_HD float GTR2_aniso(float ax, float ay, const Frame3 &frame, f3 h) {
+    float hlx2 = sqr(dot(frame.x, h)), hly2 = sqr(dot(frame.y, h)), hlz2 = sqr(dot(frame.n, h));
+    return 1.0f / (kPi * ax * ay * sqr(hlx2 / (ax * ax) + hly2 / (ay * ay) + hlz2));
+}
+LJ_HD f3 sample_visible_normals_aniso(f3 local_dir_in, float ax, float ay, float r0, float r1) {
+    bool flipped = local_dir_in.z < 0.0f;
+    if (flipped) local_dir_in = -local_dir_in;
+    f3 hemi = normalize(mk3(ax * local_dir_in.x, ay * local_dir_in.y, local_dir_in.z));
+    float r = sqrtf(r0), phi = kTwoPi * r1;
+    float t1 = r * cosf(phi), t2 = r * sinf(phi);
+    float s = (1.0f + hemi.z) * 0.5f;
+    t2 = (1.0f - s) * sqrtf(1.0f - t1 * t1) + s * t2;
+    f3 disk = mk3(t1, t2, sqrtf(fmaxf(0.0f, 1.0f - t1 * t1 - t2 * t2)));
+    f3 hn = to_world(make_frame(hemi), disk);
+    f3 n = normalize(mk3(ax * hn.x, ay * hn.y, fmaxf(0.0f, hn.z)));
+    return flipped ? -n : n;
+}
+LJ_HD float clearcoat_schlick_fresnel(f3 h, f3 dir_out) {
+    const float R_0 = 0.04f;  // ((1.5 - 1) / (1.5 + 1))^2
+    return R_0 + (1.0f - R_0) * pow5(1.0f - fabsf(dot(h, dir_out)));
+}
+LJ_HD float compute_Dc(float clearcoat_gloss, float hlz2) {
+    float a = (1.0f - clearcoat_gloss) * 0.1f + clearcoat_gloss * 0.001f, a2 = a * a;
+    return (a2 - 1.0f) / (kPi * logf(a2) * (1.0f + (a2 - 1.0f) * hlz2));
+}
+LJ_HD void aniso_alphas(float roughness, float anisotropic, float &ax, float &ay) {
+    float aspect = sqrtf(1.0f - 0.9f * anisotropic);
+    ax = fmaxf(0.0001f, roughness * roughness / aspect); ay = fmaxf(0.0001f, roughness * roughness * aspect);
+}
+LJ_HD Frame3 frame_two_sided(const DVertex &vx, f3 dir_in) {  // roughdielectric.inl:6-9
+    return (dot(vx.frame.n, dir_in) * dot(vx.gn, dir_in) < 0.0f) ? flip(vx.frame) : vx.frame;
+}
+LJ_HD f3 color_tint(f3 base_color) { float l = luminance(base_color); return l <= 0.0f ? mk3(1, 1, 1) : base_color / l; }
+LJ_HD f3 disney_diffuse_lobe(f3 base_color, float roughness, float subsurface, const Frame3 &frame, f3 dir_in, f3 dir_out) {  // disney_diffuse.inl:19-39
+    f3 h = normalize(dir_in + dir_out);
+    float h_dot_out = dot(h, dir_out), n_dot_in = dot(frame.n, dir_in), n_dot_out = dot(frame.n, dir_out);
+    float FD90 = 0.5f + 2.0f * roughness * h_dot_out * h_dot_out;
+    float FD_in = 1.0f + (FD90 - 1.0f) * (1.0f - pow5(n_dot_in)), FD_out = 1.0f + (FD90 - 1.0f) * (1.0f - pow5(n_dot_out));
+    f3 f_d = base_color * (FD_in * FD_out * fabsf(n_dot_out) * kInvPi);
+    float FSS90 = roughness * h_dot_out * h_dot_out;
+    float FSS_in = 1.0f + (FSS90 - 1.0f) * (1.0f - pow5(n_dot_in)), FSS_out = 1.0f + (FSS90 - 1.0f) * (1.0f - pow5(n_dot_out));
+    f3 f_ss = base_color * (1.25f * (FSS_in * FSS_out * (1.0f / (fabsf(n_dot_in) + fabsf(n_dot_out)) - 0.5f) + 0.5f) * fabsf(n_dot_out) * kInvPi);
+    return f_d * (1.0f - subsurface) + f_ss * subsurface;
+}
+// disney_glass.inl:3-135 (eval and pdf share everything but the last line)
+LJ_HD void disney_glass_lobe(f3 base_color, float roughness_raw, float anisotropic, float bsdf_eta, const DVertex &vx, f3 dir_in, f3 dir_out, f3 &f, float &pdf) {
+    bool reflect = dot(vx.gn, dir_in) * dot(vx.gn, dir_out) > 0.0f;
+    Frame3 frame = frame_two_sided(vx, dir_in);
+    float eta = dot(vx.gn, dir_in) > 0.0f ? bsdf_eta : 1.0f / bsdf_eta;
+    f3 h = reflect ? normalize(dir_in + dir_out) : normalize(dir_in + dir_out * eta);
+    if (dot(h, frame.n) < 0.0f) h = -h;
+    float roughness = clampf(roughness_raw, 0.01f, 1.0f);
+    float ax, ay; aniso_alphas(roughness, anisotropic, ax, ay);
+    float h_dot_in = dot(h, dir_in);
+    float F = fresnel_dielectric(h_dot_in, eta);
+    float D = GTR2_aniso(ax, ay, frame, h);
+    float G = smithG_GGX_aniso(dot(dir_in, frame.n), dot(dir_in, frame.x), dot(dir_in, frame.y), ax, ay);
+    float n_dot_in = dot(frame.n, dir_in);
+    if (reflect) {
+        pdf = (F * D * G) / (4.0f * fabsf(n_dot_in));
+        f = base_color * pdf;
+        return;
+    }
+    float h_dot_out = dot(h, dir_out);
+    float sqrt_denom = h_dot_in + eta * h_dot_out;
+    float dh_dout = eta * eta * h_dot_out / (sqrt_denom * sqrt_denom);
+    pdf = (1.0f - F) * D * G * fabsf(dh_dout * h_dot_in / n_dot_in);
+    f3 sq = mk3(sqrtf(fmaxf(base_color.x, 0.0f)), sqrtf(fmaxf(base_color.y, 0.0f)), sqrtf(fmaxf(base_color.z, 0.0f)));
+    f = sq * ((1.0f - F) * D * G * fabsf(h_dot_out * h_dot_in) / (fabsf(n_dot_in) * sqrt_denom * sqrt_denom));
+}
+LJ_HD f3 sample_clearcoat_half(float clearcoat_gloss, float r0, float r1) {  // disney_clearcoat.inl:85-97
+    float a = (1.0f - clearcoat_gloss) * 0.1f + clearcoat_gloss * 0.001f, a2 = a * a;
+    float cos_e = sqrtf((1.0f - powf(a2, 1.0f - r0)) / (1.0f - a2));
+    float sin_e = sqrtf(fmaxf(0.0f, 1.0f - cos_e * cos_e));  // sin(acos(c))
+    float az = kTwoPi * r1;
+    return normalize(mk3(sin_e * cosf(az), sin_e * sinf(az), cos_e));
+}
+
+struct BsdfSample { f3 dir_out; float eta, roughness; bool valid; };
+
+// shared tail of the dielectric samplers (roughdielectric.inl:150-176, disney_glass.inl:180-205, disney_bsdf.inl:510-535)
+LJ_HD void sample_dielectric_tail(f3 dir_in, f3 h, const Frame3 &frame, float eta, float roughness, float rnd, BsdfSample &s) {
+    if (dot(h, frame.n) < 0.0f) h = -h;
+    float h_dot_in = dot(h, dir_in);
+    float F = fresnel_dielectric(h_dot_in, eta);
+    s.roughness = roughness;
+    if (rnd <= F) { s.dir_out = normalize(-dir_in + h * (2.0f * dot(dir_in, h))); s.eta = 0.0f; s.valid = true; return; }
+    float h_dot_out_sq = 1.0f - (1.0f - h_dot_in * h_dot_in) / (eta * eta);
+    if (h_dot_out_sq <= 0.0f) { s.valid = false; return; }
+    if (h_dot_in < 0.0f) h = -h;
+    float h_dot_out = sqrtf(h_dot_out_sq);
+    s.dir_out = -dir_in / eta + h * (fabsf(h_dot_in) / eta - h_dot_out); s.eta = eta; s.valid = true;
+}
+
 
 // eval (BSDF * |cos|) and pdf together: the integrator always needs both for the same pair of directions
 // (path_tracing.h:166,187 and :251-252).
 LJ_HD void bsdf_eval_pdf(const DScene &sc, const DMaterial &m, f3 dir_in, f3 dir_out, const DVertex &vx, f3 &f, float &pdf) {
     f = mk3(0, 0, 0); pdf = 0.0f;
-    if (dot(vx.gn, dir_in) < 0.0f || dot(vx.gn, dir_out) < 0.0f) return;  // lambertian.inl:2-6, roughplastic.inl:4-8
+    const bool above = !(dot(vx.gn, dir_in) < 0.0f || dot(vx.gn, dir_out) < 0.0f);
+    if (m.kind == 2) {  // roughdielectric.inl:3-88 (TransportDirection::TO_LIGHT, the only one path_tracing uses)
+        bool reflect = dot(vx.gn, dir_in) * dot(vx.gn, dir_out) > 0.0f;
+        Frame3 frame = frame_two_sided(vx, dir_in);
+        float eta = dot(vx.gn, dir_in) > 0.0f ? m.eta : 1.0f / m.eta;
+        f3 h = reflect ? normalize(dir_in + dir_out) : normalize(dir_in + dir_out * eta);
+        if (dot(h, frame.n) < 0.0f) h = -h;
+        float roughness = clampf(tex1(sc, m, 2, vx), 0.01f, 1.0f);
+        float h_dot_in = dot(h, dir_in);
+        float F = fresnel_dielectric(h_dot_in, eta);
+        float D = GTR2(dot(frame.n, h), roughness);
+        float G_in = smith_masking_gtr2(to_local(frame, dir_in), roughness);
+        float G = G_in * smith_masking_gtr2(to_local(frame, dir_out), roughness);
+        float n_dot_in = dot(frame.n, dir_in);
+        if (reflect) {
+            f = tex3(sc, m, 0, vx) * ((F * D * G) / (4.0f * fabsf(n_dot_in)));
+            pdf = (F * D * G_in) / (4.0f * fabsf(n_dot_in));
+        } else {
+            float h_dot_out = dot(h, dir_out);
+            float sqrt_denom = h_dot_in + eta * h_dot_out;
+            f = tex3(sc, m, 1, vx) * (((1.0f / (eta * eta)) * (1.0f - F) * D * G * eta * eta * fabsf(h_dot_out * h_dot_in)) / (fabsf(n_dot_in) * sqrt_denom * sqrt_denom));
+            float dh_dout = eta * eta * h_dot_out / (sqrt_denom * sqrt_denom);
+            pdf = (1.0f - F) * D * G_in * fabsf(dh_dout * h_dot_in / n_dot_in);
+        }
+        return;
+    }
+    if (m.kind == 5) {  // disney_glass.inl
+        disney_glass_lobe(tex3(sc, m, 0, vx), tex1(sc, m, 1, vx), tex1(sc, m, 2, vx), m.eta, vx, dir_in, dir_out, f, pdf);
+        return;
+    }
+    if (m.kind == 8) {  // disney_bsdf.inl:3-372
+        f3 base_color = tex3(sc, m, 0, vx);
+        float specular_transmission = tex1(sc, m, 1, vx), metallic = tex1(sc, m, 2, vx), subsurface = tex1(sc, m, 3, vx), specular = tex1(sc, m, 4, vx);
+        float roughness_raw = tex1(sc, m, 5, vx), specular_tint = tex1(sc, m, 6, vx), anisotropic = tex1(sc, m, 7, vx), sheen = tex1(sc, m, 8, vx);
+        float sheen_tint = tex1(sc, m, 9, vx), clearcoat = tex1(sc, m, 10, vx), clearcoat_gloss = tex1(sc, m, 11, vx);
+        const bool inside = dot(vx.gn, dir_in) < 0.0f;
+        const bool reflect = dot(vx.gn, dir_in) * dot(vx.gn, dir_out) > 0.0f;
+        f3 f_glass; float glass_pdf;
+        disney_glass_lobe(base_color, roughness_raw, anisotropic, m.eta, vx, dir_in, dir_out, f_glass, glass_pdf);
+        float diffuse_weight = (1.0f - metallic) * (1.0f - specular_transmission);
+        float metal_weight = 1.0f - specular_transmission * (1.0f - metallic);
+        float glass_weight = (1.0f - metallic) * specular_transmission;
+        float clearcoat_weight = 0.25f * clearcoat;
+        f = f_glass * glass_weight;
+        bool pdf_zero = false;
+        if (inside) { diffuse_weight = metal_weight = clearcoat_weight = 0.0f; if (glass_weight > 0.0f) glass_weight = 1.0f; else pdf_zero = true; }
+        float wsum = diffuse_weight + metal_weight + glass_weight + clearcoat_weight;
+        Frame3 frame = vx.frame;
+        if (dot(frame.n, dir_in) < 0.0f) frame = flip(frame);
+        f3 h = normalize(dir_in + dir_out);
+        float roughness = clampf(roughness_raw, 0.01f, 1.0f);
+        float ax, ay; aniso_alphas(roughness, anisotropic, ax, ay);
+        float Dm = GTR2_aniso(ax, ay, frame, h);
+        float n_dot_in = dot(dir_in, frame.n);
+        float Gin = smithG_GGX_aniso(n_dot_in, dot(dir_in, frame.x), dot(dir_in, frame.y), ax, ay);
+        float n_dot_h = dot(frame.n, h);
+        float Dc = compute_Dc(clearcoat_gloss, n_dot_h * n_dot_h);
+        if (!pdf_zero) {
+            if (reflect) {
+                float diffuse_pdf = fmaxf(dot(frame.n, dir_out), 0.0f) * kInvPi;
+                float metal_pdf = Dm * Gin / (4.0f * fabsf(n_dot_in));
+                float clearcoat_pdf = Dc * fabsf(n_dot_h) / (4.0f * fabsf(dot(h, dir_out)));
+                pdf = (diffuse_weight * diffuse_pdf + metal_weight * metal_pdf + clearcoat_weight * clearcoat_pdf + glass_weight * glass_pdf) / wsum;
+            } else pdf = glass_weight * glass_pdf / wsum;
+        }
+        if (!inside && dot(vx.gn, dir_out) >= 0.0f) {  // the four reflective lobes (disney_bsdf.inl:24-129)
+            f3 f_diffuse = disney_diffuse_lobe(base_color, roughness_raw, subsurface, frame, dir_in, dir_out);
+            float h_dot_out = dot(h, dir_out);
+            f3 C_tint = color_tint(base_color);
+            f3 Ks = mk3(1, 1, 1) * (1.0f - specular_tint) + C_tint * specular_tint;
+            f3 C0 = Ks * (specular * 0.04f * (1.0f - metallic)) + base_color * metallic;
+            f3 Fm = C0 + (mk3(1, 1, 1) - C0) * pow5(1.0f - h_dot_out);  // no fabs here, as written (disney_bsdf.inl:77)
+            float Gout = smithG_GGX_aniso(dot(dir_out, frame.n), dot(dir_out, frame.x), dot(dir_out, frame.y), ax, ay);
+            f3 f_metal = Fm * (Dm * Gin * Gout / (4.0f * fabsf(n_dot_in)));
+            float f_clearcoat = 0.0f;
+            if (n_dot_h > 0.0f) {
+                float G = smith_masking_gtr2(to_local(frame, dir_in), 0.5f) * smith_masking_gtr2(to_local(frame, dir_out), 0.5f);
+                f_clearcoat = clearcoat_schlick_fresnel(h, dir_out) * Dc * G / (4.0f * fabsf(n_dot_in));
+            }
+            f3 C_sheen = mk3(1, 1, 1) * (1.0f - sheen_tint) + C_tint * sheen_tint;
+            f3 f_sheen = C_sheen * (pow5(1.0f - fabsf(h_dot_out)) * fabsf(dot(frame.n, dir_out)));
+            f = f + f_diffuse * ((1.0f - specular_transmission) * (1.0f - metallic)) + f_sheen * ((1.0f - metallic) * sheen)
+                  + f_metal * (1.0f - specular_transmission * (1.0f - metallic)) + mk3(1, 1, 1) * (0.25f * clearcoat * f_clearcoat);
+        }
+        return;
+    }
+    if (!above) return;  // one-sided materials: no light below the surface (lambertian.inl:2-6 and the like)
     Frame3 frame = vx.frame;
     if (dot(frame.n, dir_in) < 0.0f) frame = flip(frame);
     float n_dot_out = dot(frame.n, dir_out);
+    if (m.kind == 3 || m.kind == 7) {  // disney_diffuse.inl:1-58, disney_sheen.inl:3-46
+        pdf = fmaxf(n_dot_out, 0.0f) * kInvPi;
+        if (m.kind == 3) f = disney_diffuse_lobe(tex3(sc, m, 0, vx), tex1(sc, m, 1, vx), tex1(sc, m, 2, vx), frame, dir_in, dir_out);
+        else {
+            f3 h = normalize(dir_in + dir_out);
+            float sheen_tint = tex1(sc, m, 1, vx);
+            f3 C_sheen = mk3(1, 1, 1) * (1.0f - sheen_tint) + color_tint(tex3(sc, m, 0, vx)) * sheen_tint;
+            f = C_sheen * (pow5(1.0f - fabsf(dot(h, dir_out))) * fabsf(n_dot_out));
+        }
+        return;
+    }
+    if (m.kind == 4) {  // disney_metal.inl:52-126
+        f3 base_color = tex3(sc, m, 0, vx);
+        float roughness = clampf(tex1(sc, m, 1, vx), 0.01f, 1.0f), anisotropic = tex1(sc, m, 2, vx);
+        f3 h = normalize(dir_in + dir_out);
+        f3 Fm = base_color + (mk3(1, 1, 1) - base_color) * pow5(1.0f - fabsf(dot(h, dir_out)));
+        float ax, ay; aniso_alphas(roughness, anisotropic, ax, ay);
+        float Dm = GTR2_aniso(ax, ay, frame, h);
+        float n_dot_in = dot(dir_in, frame.n);
+        float Gin = smithG_GGX_aniso(n_dot_in, dot(dir_in, frame.x), dot(dir_in, frame.y), ax, ay);
+        float Gout = smithG_GGX_aniso(n_dot_out, dot(dir_out, frame.x), dot(dir_out, frame.y), ax, ay);
+        pdf = Dm * Gin / (4.0f * fabsf(n_dot_in));
+        f = Fm * (pdf * Gout);
+        return;
+    }
+    if (m.kind == 6) {  // disney_clearcoat.inl:18-66
+        f3 h = normalize(dir_in + dir_out);
+        float n_dot_h = dot(frame.n, h);
+        float D = compute_Dc(tex1(sc, m, 0, vx), n_dot_h * n_dot_h);
+        pdf = D * fabsf(n_dot_h) / (4.0f * fabsf(dot(h, dir_out)));
+        if (n_dot_h > 0.0f) {
+            float G = smith_masking_gtr2(to_local(frame, dir_in), 0.5f) * smith_masking_gtr2(to_local(frame, dir_out), 0.5f);
+            float v = clearcoat_schlick_fresnel(h, dir_out) * D * G / (4.0f * fabsf(dot(frame.n, dir_in)));
+            f = mk3(v, v, v);
+        }
+        return;
+    }
     if (m.kind == 0) {  // lambertian.inl:1-33
         float c = fmaxf(n_dot_out, 0.0f);
         f = tex3(sc, m, 0, vx) * (c * kInvPi);
@@ -320,9 +544,78 @@ LJ_HD void bsdf_eval_pdf(const DScene &sc, const DMaterial &m, f3 dir_in, f3 dir
 
 LJ_HD BsdfSample bsdf_sample(const DScene &sc, const DMaterial &m, f3 dir_in, const DVertex &vx, float r0, float r1, float rw) {
     BsdfSample s; s.valid = false; s.eta = 0.0f; s.roughness = 1.0f; s.dir_out = mk3(0, 0, 0);
-    if (dot(vx.gn, dir_in) < 0.0f) return s;  // lambertian.inl:37-40, roughplastic.inl:112-115
+    if (m.kind == 2) {  // roughdielectric.inl:90-177
+        float eta = dot(vx.gn, dir_in) > 0.0f ? m.eta : 1.0f / m.eta;
+        Frame3 fr = frame_two_sided(vx, dir_in);
+        float roughness = clampf(tex1(sc, m, 2, vx), 0.01f, 1.0f);
+        f3 h = to_world(fr, sample_visible_normals(to_local(fr, dir_in), roughness * roughness, r0, r1));
+        sample_dielectric_tail(dir_in, h, fr, eta, roughness, rw, s);
+        return s;
+    }
+    if (m.kind == 5) {  // disney_glass.inl:137-205
+        Frame3 fr = frame_two_sided(vx, dir_in);
+        float eta = dot(vx.gn, dir_in) > 0.0f ? m.eta : 1.0f / m.eta;
+        float roughness = clampf(tex1(sc, m, 1, vx), 0.01f, 1.0f);
+        float ax, ay; aniso_alphas(roughness, tex1(sc, m, 2, vx), ax, ay);
+        f3 h = to_world(fr, sample_visible_normals_aniso(to_local(fr, dir_in), ax, ay, r0, r1));
+        sample_dielectric_tail(dir_in, h, fr, eta, roughness, rw, s);
+        return s;
+    }
+    if (m.kind == 8) {  // disney_bsdf.inl:374-572
+        float specular_transmission = tex1(sc, m, 1, vx), metallic = tex1(sc, m, 2, vx), anisotropic = tex1(sc, m, 7, vx);
+        float clearcoat = tex1(sc, m, 10, vx);
+        float eta = dot(vx.gn, dir_in) > 0.0f ? m.eta : 1.0f / m.eta;
+        float diffuse_weight = (1.0f - metallic) * (1.0f - specular_transmission);
+        float metal_weight = 1.0f - specular_transmission * (1.0f - metallic);
+        float glass_weight = (1.0f - metallic) * specular_transmission;
+        float clearcoat_weight = 0.25f * clearcoat;
+        if (dot(vx.gn, dir_in) < 0.0f) {
+            diffuse_weight = metal_weight = clearcoat_weight = 0.0f;
+            if (glass_weight > 0.0f) glass_weight = 1.0f;
+            else { s.valid = true; return s; }  // zero-direction record, not nullopt (disney_bsdf.inl:418-420); its pdf is 0
+        }
+        float wsum = diffuse_weight + metal_weight + glass_weight + clearcoat_weight;
+        diffuse_weight /= wsum; metal_weight /= wsum; glass_weight /= wsum;
+        Frame3 fr = vx.frame;
+        if (dot(fr.n, dir_in) < 0.0f) fr = flip(fr);
+        if (rw < diffuse_weight) { s.dir_out = to_world(fr, sample_cos_hemisphere(r0, r1)); s.valid = true; }
+        else if (rw < diffuse_weight + metal_weight) {
+            float roughness = clampf(tex1(sc, m, 5, vx), 0.01f, 1.0f);
+            float ax, ay; aniso_alphas(roughness, anisotropic, ax, ay);
+            f3 h = to_world(fr, sample_visible_normals_aniso(to_local(fr, dir_in), ax, ay, r0, r1));
+            s.dir_out = normalize(-dir_in + h * (2.0f * dot(dir_in, h))); s.roughness = roughness; s.valid = true;
+        } else if (rw < diffuse_weight + metal_weight + glass_weight) {
+            Frame3 f2 = frame_two_sided(vx, dir_in);
+            float roughness = clampf(tex1(sc, m, 5, vx), 0.01f, 1.0f);
+            float ax, ay; aniso_alphas(roughness, anisotropic, ax, ay);
+            f3 h = to_world(f2, sample_visible_normals_aniso(to_local(f2, dir_in), ax, ay, r0, r1));
+            float rand_new = (rw - (diffuse_weight + metal_weight)) / glass_weight;
+            sample_dielectric_tail(dir_in, h, f2, eta, roughness, rand_new, s);
+        } else {
+            f3 h = to_world(fr, sample_clearcoat_half(tex1(sc, m, 11, vx), r0, r1));
+            s.dir_out = normalize(-dir_in + h * (2.0f * dot(dir_in, h))); s.valid = true;
+        }
+        return s;
+    }
+    if (dot(vx.gn, dir_in) < 0.0f) return s;  // one-sided materials (lambertian.inl:37-40 and the like)
     Frame3 frame = vx.frame;
     if (dot(frame.n, dir_in) < 0.0f) frame = flip(frame);
+    if (m.kind == 3 || m.kind == 7) {  // disney_diffuse.inl:60-76, disney_sheen.inl:48-62
+        s.dir_out = to_world(frame, sample_cos_hemisphere(r0, r1)); s.valid = true;
+        return s;
+    }
+    if (m.kind == 4) {  // disney_metal.inl:128-162
+        float roughness = clampf(tex1(sc, m, 1, vx), 0.01f, 1.0f);
+        float ax, ay; aniso_alphas(roughness, tex1(sc, m, 2, vx), ax, ay);
+        f3 h = to_world(frame, sample_visible_normals_aniso(to_local(frame, dir_in), ax, ay, r0, r1));
+        s.dir_out = normalize(-dir_in + h * (2.0f * dot(dir_in, h))); s.roughness = roughness; s.valid = true;
+        return s;
+    }
+    if (m.kind == 6) {  // disney_clearcoat.inl:68-106
+        f3 h = to_world(frame, sample_clearcoat_half(tex1(sc, m, 0, vx), r0, r1));
+        s.dir_out = normalize(-dir_in + h * (2.0f * dot(dir_in, h))); s.valid = true;
+        return s;
+    }
     if (m.kind == 0) {  // lambertian.inl:35-50
         s.dir_out = to_world(frame, sample_cos_hemisphere(r0, r1)); s.valid = true;
         return s;
@@ -344,7 +637,7 @@ LJ_HD BsdfSample bsdf_sample(const DScene &sc, const DMaterial &m, f3 dir_in, co
     return s;
 }
 
-LJ_HD bool material_supported(int kind) { return kind == 0 || kind == 1; }
+LJ_HD bool material_supported(int kind) { return kind >= 0 && kind <= 8; }
 
 // ------------------------------------------------------------------ the per-path record the kernels move
 struct PathState {

@@ -116,8 +116,8 @@ FlatScene flatten_scene(const LjSceneDesc &d) {
         if (sh.material_id >= 0) {
             if (sh.material_id >= d.n_materials) throw LjError(LJ_ERR_INVALID_ARG, "shape references a missing material");
             int kind = d.materials[sh.material_id].kind;
-            if (!(kind == LJ_MAT_LAMBERTIAN || kind == LJ_MAT_ROUGHPLASTIC))
-                throw LjError(LJ_ERR_UNSUPPORTED, "material alternative " + std::to_string(kind) + " (material.h:102-110) is not implemented on the device yet");
+            if (kind < LJ_MAT_LAMBERTIAN || kind > LJ_MAT_DISNEYBSDF)
+                throw LjError(LJ_ERR_UNSUPPORTED, "material alternative " + std::to_string(kind) + " (material.h:102-110) is not implemented on the device");
         } else throw LjError(LJ_ERR_INVALID_ARG, "shape " + std::to_string(si) + " has no material (the reference asserts material_id >= 0, path_tracing.h:165)");
         if (sh.kind == LJ_SHAPE_SPHERE) {
             ljd::DSphere ds; for (int k = 0; k < 3; k++) ds.center[k] = sh.position[k]; ds.radius = sh.radius;

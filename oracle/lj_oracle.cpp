@@ -11,7 +11,7 @@
 //   PINNED  by tests/golden/*.json, produced by the reference's own functions compiled from /root/reference
 //           (oracle/ref_build.sh, oracle/gen_golden.cpp): pcg32, filters, camera rays, frames, table
 //           distributions, ray differentials, light selection / sampling / pdf / emission, triangle + sphere
-//           shading info (PathVertex), Lambertian + RoughPlastic eval / pdf / sample, scene tables.
+//           shading info (PathVertex), eval / pdf / sample of all nine Material alternatives, scene tables.
 //   UNPINNED against the reference: the ray/scene intersection itself (Embree 3.13.2 is a binary-only
 //           dependency whose Linux library is absent from /root/reference) and therefore path_tracing()
 //           end-to-end.  The bounce loop below is a line-by-line restatement of path_tracing.h:7-325 over
@@ -562,12 +562,126 @@ Vector3 sample_visible_normals(const Vector3 &local_dir_in, Real alpha, const Ve
     return normalize(Vector3{alpha * hemi_N.x, alpha * hemi_N.y, std::max(Real(0), hemi_N.z)});
 }
 
-struct BSDFSampleRecord { Vector3 dir_out; Real eta, roughness; };
 inline Spectrum tex3(const OScene *s, const LjMaterial &m, int slot, const PathVertex &v) { return eval_texture(s, m.tex[slot], true, v.uv, v.uv_screen_size); }
+struct BSDFSampleRecord { Vector3 dir_out; Real eta, roughness; };
 inline Real tex1(const OScene *s, const LjMaterial &m, int slot, const PathVertex &v) { return eval_texture(s, m.tex[slot], false, v.uv, v.uv_screen_size).x; }
 
+// ---- Disney BSDF family helpers (materials/disney_metal.inl:3-50, disney_clearcoat.inl:3-16)
+inline Real smithG_GGX_aniso(Real NdotW, Real WdotX, Real WdotY, Real ax, Real ay) {  // disney_metal.inl:3-8
+    Real lambda = Real(0.5) * (std::sqrt(Real(1) + (std::pow(WdotX * ax, 2) + std::pow(WdotY * ay, 2)) / std::pow(NdotW, 2)) - Real(1));
+    return Real(1) / (Real(1) + lambda);
+}
+inline Real GTR2_aniso(Real ax, Real ay, const Frame &frame, const Vector3 &h) {  // disney_metal.inl:10-19
+    Real ax2 = ax * ax, ay2 = ay * ay;
+    Real hlx2 = std::pow(dot(frame.x, h), 2), hly2 = std::pow(dot(frame.y, h), 2), hlz2 = std::pow(dot(frame.n, h), 2);
+    return Real(1) / (c_PI * ax * ay * std::pow(hlx2 / ax2 + hly2 / ay2 + hlz2, 2));
+}
+Vector3 sample_visible_normals_aniso(const Vector3 &local_dir_in, Real ax, Real ay, const Vector2 &rnd) {  // disney_metal.inl:21-50
+    if (local_dir_in.z < 0) return -sample_visible_normals_aniso(-local_dir_in, ax, ay, rnd);
+    Vector3 hemi_dir_in = normalize(Vector3{ax * local_dir_in.x, ay * local_dir_in.y, local_dir_in.z});
+    Real r = std::sqrt(rnd.x), phi = 2 * c_PI * rnd.y;
+    Real t1 = r * std::cos(phi), t2 = r * std::sin(phi);
+    Real s = (1 + hemi_dir_in.z) / 2;
+    t2 = (1 - s) * std::sqrt(1 - t1 * t1) + s * t2;
+    Vector3 disk_N{t1, t2, std::sqrt(std::max(Real(0), 1 - t1 * t1 - t2 * t2))};
+    Vector3 hemi_N = to_world(make_frame(hemi_dir_in), disk_N);
+    return normalize(Vector3{ax * hemi_N.x, ay * hemi_N.y, std::max(Real(0), hemi_N.z)});
+}
+inline Real clearcoat_schlick_fresnel(const Vector3 &half_vector, const Vector3 &dir_out) {  // disney_clearcoat.inl:3-8
+    Real eta = Real(1.5);
+    Real R_0 = std::pow(eta - Real(1), 2) / std::pow(eta + Real(1), 2);
+    return R_0 + (Real(1) - R_0) * std::pow(Real(1) - std::fabs(dot(half_vector, dir_out)), 5);
+}
+inline Real compute_Dc(Real clearcoat_gloss, Real hlz2) {  // disney_clearcoat.inl:10-16
+    Real a = (Real(1) - clearcoat_gloss) * Real(0.1) + clearcoat_gloss * Real(0.001);
+    Real a2 = a * a;
+    return (a2 - Real(1)) / (c_PI * std::log(a2) * (Real(1) + (a2 - Real(1)) * hlz2));
+}
+inline void aniso_alphas(Real roughness, Real anisotropic, Real &ax, Real &ay) {  // disney_metal.inl:75-78 (and glass / bsdf copies)
+    Real aspect = std::sqrt(Real(1) - Real(0.9) * anisotropic);
+    Real a_min = Real(0.0001);
+    ax = std::fmax(a_min, roughness * roughness / aspect);
+    ay = std::fmax(a_min, roughness * roughness * aspect);
+}
+inline Frame frame_to_dir_in(const PathVertex &vertex, const Vector3 &dir_in) {  // "flip the shading frame" idiom (lambertian.inl:10-13)
+    Frame frame = vertex.shading_frame;
+    if (dot(frame.n, dir_in) < 0) frame = -frame;
+    return frame;
+}
+inline Frame frame_two_sided(const PathVertex &vertex, const Vector3 &dir_in) {  // roughdielectric.inl:6-9 / disney_glass.inl:6-9
+    Frame frame = vertex.shading_frame;
+    if (dot(frame.n, dir_in) * dot(vertex.geometry_normal, dir_in) < 0) frame = -frame;
+    return frame;
+}
+// the five lobes of disney_bsdf.inl, which are also (verbatim) the bodies of the five standalone Disney materials
+Spectrum disney_diffuse_lobe(const Spectrum &base_color, Real roughness, Real subsurface, const Frame &frame, const Vector3 &dir_in, const Vector3 &dir_out) {
+    Vector3 half_vector = normalize(dir_in + dir_out);  // disney_diffuse.inl:19-39 / disney_bsdf.inl:33-52
+    Real h_dot_out = dot(half_vector, dir_out), n_dot_in = dot(frame.n, dir_in), n_dot_out = dot(frame.n, dir_out);
+    Real FD90 = Real(0.5) + Real(2) * roughness * h_dot_out * h_dot_out;
+    Real FD_in = Real(1) + (FD90 - Real(1)) * (Real(1) - std::pow(n_dot_in, 5));   // pow(n.w, 5), not pow(1 - n.w, 5): as written
+    Real FD_out = Real(1) + (FD90 - Real(1)) * (Real(1) - std::pow(n_dot_out, 5));
+    Spectrum f_d = base_color * FD_in * FD_out * std::fabs(n_dot_out) / c_PI;
+    Real FSS90 = roughness * h_dot_out * h_dot_out;
+    Real FSS_in = Real(1) + (FSS90 - Real(1)) * (Real(1) - std::pow(n_dot_in, 5));
+    Real FSS_out = Real(1) + (FSS90 - Real(1)) * (Real(1) - std::pow(n_dot_out, 5));
+    Spectrum f_ss = Real(1.25) * base_color * (FSS_in * FSS_out * (Real(1) / (std::fabs(n_dot_in) + std::fabs(n_dot_out)) - Real(0.5)) + Real(0.5)) * std::fabs(n_dot_out) / c_PI;
+    return (Real(1) - subsurface) * f_d + subsurface * f_ss;
+}
+Spectrum disney_glass_lobe(const Spectrum &base_color, Real roughness_raw, Real anisotropic, Real bsdf_eta, const PathVertex &vertex, const Vector3 &dir_in, const Vector3 &dir_out, Real *pdf_out) {
+    bool reflect = dot(vertex.geometry_normal, dir_in) * dot(vertex.geometry_normal, dir_out) > 0;  // disney_glass.inl:3-83,85-135
+    Frame frame = frame_two_sided(vertex, dir_in);
+    Real eta = dot(vertex.geometry_normal, dir_in) > 0 ? bsdf_eta : 1 / bsdf_eta;
+    Vector3 half_vector = reflect ? normalize(dir_in + dir_out) : normalize(dir_in + dir_out * eta);
+    if (dot(half_vector, frame.n) < 0) half_vector = -half_vector;
+    Real roughness = clampr(roughness_raw, Real(0.01), Real(1));
+    Real ax, ay; aniso_alphas(roughness, anisotropic, ax, ay);
+    Real h_dot_in = dot(half_vector, dir_in);
+    Real F = fresnel_dielectric(h_dot_in, eta);
+    Real D = GTR2_aniso(ax, ay, frame, half_vector);
+    Real G = smithG_GGX_aniso(dot(dir_in, frame.n), dot(dir_in, frame.x), dot(dir_in, frame.y), ax, ay);  // G_in only (disney_glass.inl:59)
+    if (reflect) {
+        if (pdf_out) *pdf_out = (F * D * G) / (4 * std::fabs(dot(frame.n, dir_in)));
+        return base_color * (F * D * G) / (4 * std::fabs(dot(frame.n, dir_in)));
+    }
+    Real h_dot_out = dot(half_vector, dir_out);
+    if (pdf_out) {
+        Real sqrt_denom = h_dot_in + eta * h_dot_out;
+        Real dh_dout = eta * eta * h_dot_out / (sqrt_denom * sqrt_denom);
+        *pdf_out = (1 - F) * D * G * std::fabs(dh_dout * h_dot_in / dot(frame.n, dir_in));
+    }
+    Spectrum sq{std::sqrt(std::max(base_color.x, Real(0))), std::sqrt(std::max(base_color.y, Real(0))), std::sqrt(std::max(base_color.z, Real(0)))};  // spectrum.h:22-26
+    return sq * (Real(1) - F) * D * G * std::fabs(h_dot_out * h_dot_in) / (std::fabs(dot(frame.n, dir_in)) * std::pow(h_dot_in + eta * h_dot_out, 2));
+}
+// shared tail of the glass samplers (disney_glass.inl:167-205, disney_bsdf.inl:488-535, roughdielectric.inl:150-176)
+bool sample_dielectric_tail(const Vector3 &dir_in, Vector3 half_vector, const Frame &frame, Real eta, Real roughness, Real rnd, BSDFSampleRecord &rec) {
+    if (dot(half_vector, frame.n) < 0) half_vector = -half_vector;
+    Real h_dot_in = dot(half_vector, dir_in);
+    Real F = fresnel_dielectric(h_dot_in, eta);
+    if (rnd <= F) {
+        rec = {normalize(-dir_in + 2 * dot(dir_in, half_vector) * half_vector), Real(0), roughness};
+        return true;
+    }
+    Real h_dot_out_sq = 1 - (1 - h_dot_in * h_dot_in) / (eta * eta);
+    if (h_dot_out_sq <= 0) return false;
+    if (h_dot_in < 0) half_vector = -half_vector;
+    Real h_dot_out = std::sqrt(h_dot_out_sq);
+    rec = {-dir_in / eta + (std::fabs(h_dot_in) / eta - h_dot_out) * half_vector, eta, roughness};
+    return true;
+}
+inline Spectrum color_tint(const Spectrum &base_color) {  // disney_sheen.inl:24-25
+    if (luminance(base_color) <= 0) return {1, 1, 1};
+    return base_color / luminance(base_color);
+}
+inline Vector3 sample_clearcoat_half(Real clearcoat_gloss, const Vector2 &rnd) {  // disney_clearcoat.inl:85-97
+    Real a = (Real(1) - clearcoat_gloss) * Real(0.1) + clearcoat_gloss * Real(0.001);
+    Real a2 = a * a;
+    Real cos_h_elevation = std::sqrt((Real(1) - std::pow(a2, Real(1) - rnd.x)) / (Real(1) - a2));
+    Real h_elevation = std::acos(cos_h_elevation), h_azimuth = Real(2) * c_PI * rnd.y;
+    return normalize(Vector3{std::sin(h_elevation) * std::cos(h_azimuth), std::sin(h_elevation) * std::sin(h_azimuth), std::cos(h_elevation)});
+}
+
 // returns false for material kinds the oracle does not restate yet
-bool bsdf_eval(const OScene *s, const LjMaterial &m, const Vector3 &dir_in, const Vector3 &dir_out, const PathVertex &vertex, Spectrum &out) {
+bool bsdf_eval(const OScene *s, const LjMaterial &m, const Vector3 &dir_in, const Vector3 &dir_out, const PathVertex &vertex, Spectrum &out, bool to_view = false) {
     out = {0, 0, 0};
     if (m.kind == LJ_MAT_LAMBERTIAN) {  // lambertian.inl:1-17
         if (dot(vertex.geometry_normal, dir_in) < 0 || dot(vertex.geometry_normal, dir_out) < 0) return true;
@@ -592,6 +706,129 @@ bool bsdf_eval(const OScene *s, const LjMaterial &m, const Vector3 &dir_in, cons
         Real F_i = fresnel_dielectric(dot(half_vector, dir_in), m.eta);
         Spectrum diffuse_contrib = Kd * (Real(1) - F_o) * (Real(1) - F_i) / c_PI;
         out = (spec_contrib + diffuse_contrib) * n_dot_out;
+        return true;
+    }
+
+    const bool above = !(dot(vertex.geometry_normal, dir_in) < 0 || dot(vertex.geometry_normal, dir_out) < 0);
+    if (m.kind == LJ_MAT_ROUGHDIELECTRIC) {  // roughdielectric.inl:3-47
+        bool reflect = dot(vertex.geometry_normal, dir_in) * dot(vertex.geometry_normal, dir_out) > 0;
+        Frame frame = frame_two_sided(vertex, dir_in);
+        Real eta = dot(vertex.geometry_normal, dir_in) > 0 ? m.eta : 1 / m.eta;
+        Spectrum Ks = tex3(s, m, 0, vertex), Kt = tex3(s, m, 1, vertex);
+        Real roughness = tex1(s, m, 2, vertex);
+        Vector3 half_vector = reflect ? normalize(dir_in + dir_out) : normalize(dir_in + dir_out * eta);
+        if (dot(half_vector, frame.n) < 0) half_vector = -half_vector;
+        roughness = clampr(roughness, Real(0.01), Real(1));
+        Real h_dot_in = dot(half_vector, dir_in);
+        Real F = fresnel_dielectric(h_dot_in, eta);
+        Real D = GTR2(dot(frame.n, half_vector), roughness);
+        Real G = smith_masking_gtr2(to_local(frame, dir_in), roughness) * smith_masking_gtr2(to_local(frame, dir_out), roughness);
+        if (reflect) out = Ks * (F * D * G) / (4 * std::fabs(dot(frame.n, dir_in)));
+        else {
+            Real eta_factor = to_view ? 1 : (1 / (eta * eta));
+            Real h_dot_out = dot(half_vector, dir_out);
+            Real sqrt_denom = h_dot_in + eta * h_dot_out;
+            out = Kt * (eta_factor * (1 - F) * D * G * eta * eta * std::fabs(h_dot_out * h_dot_in)) / (std::fabs(dot(frame.n, dir_in)) * sqrt_denom * sqrt_denom);
+        }
+        return true;
+    }
+    if (m.kind == LJ_MAT_DISNEYDIFFUSE) {  // disney_diffuse.inl:1-42
+        if (!above) return true;
+        out = disney_diffuse_lobe(tex3(s, m, 0, vertex), tex1(s, m, 1, vertex), tex1(s, m, 2, vertex), frame_to_dir_in(vertex, dir_in), dir_in, dir_out);
+        return true;
+    }
+    if (m.kind == LJ_MAT_DISNEYMETAL) {  // disney_metal.inl:52-93
+        if (!above) return true;
+        Frame frame = frame_to_dir_in(vertex, dir_in);
+        Spectrum base_color = tex3(s, m, 0, vertex);
+        Real roughness = clampr(tex1(s, m, 1, vertex), Real(0.01), Real(1)), anisotropic = tex1(s, m, 2, vertex);
+        Vector3 half_vector = normalize(dir_in + dir_out);
+        Real h_dot_out = dot(half_vector, dir_out);
+        Spectrum Fm = base_color + (Vector3{1, 1, 1} - base_color) * std::pow(Real(1) - std::fabs(h_dot_out), 5);
+        Real ax, ay; aniso_alphas(roughness, anisotropic, ax, ay);
+        Real Dm = GTR2_aniso(ax, ay, frame, half_vector);
+        Real Gin = smithG_GGX_aniso(dot(dir_in, frame.n), dot(dir_in, frame.x), dot(dir_in, frame.y), ax, ay);
+        Real Gout = smithG_GGX_aniso(dot(dir_out, frame.n), dot(dir_out, frame.x), dot(dir_out, frame.y), ax, ay);
+        out = Fm * Dm * Gin * Gout / (Real(4) * std::fabs(dot(dir_in, frame.n)));
+        return true;
+    }
+    if (m.kind == LJ_MAT_DISNEYGLASS) {  // disney_glass.inl:3-83
+        out = disney_glass_lobe(tex3(s, m, 0, vertex), tex1(s, m, 1, vertex), tex1(s, m, 2, vertex), m.eta, vertex, dir_in, dir_out, nullptr);
+        return true;
+    }
+    if (m.kind == LJ_MAT_DISNEYCLEARCOAT) {  // disney_clearcoat.inl:18-45
+        if (!above) return true;
+        Frame frame = frame_to_dir_in(vertex, dir_in);
+        Vector3 half_vector = normalize(dir_in + dir_out);
+        Real n_dot_h = dot(frame.n, half_vector), n_dot_in = dot(frame.n, dir_in);
+        if (n_dot_h <= 0) return true;
+        Real F = clearcoat_schlick_fresnel(half_vector, dir_out);
+        Real D = compute_Dc(tex1(s, m, 0, vertex), std::pow(dot(frame.n, half_vector), 2));
+        Real G = smith_masking_gtr2(to_local(frame, dir_in), Real(0.5)) * smith_masking_gtr2(to_local(frame, dir_out), Real(0.5));
+        Real v = F * D * G / (Real(4) * std::fabs(n_dot_in));
+        out = {v, v, v};
+        return true;
+    }
+    if (m.kind == LJ_MAT_DISNEYSHEEN) {  // disney_sheen.inl:3-31
+        if (!above) return true;
+        Frame frame = frame_to_dir_in(vertex, dir_in);
+        Spectrum base_color = tex3(s, m, 0, vertex); Real sheen_tint = tex1(s, m, 1, vertex);
+        Vector3 half_vector = normalize(dir_in + dir_out);
+        Real n_dot_out = dot(frame.n, dir_out);
+        Spectrum C_sheen = Vector3{1, 1, 1} * (Real(1) - sheen_tint) + sheen_tint * color_tint(base_color);
+        out = C_sheen * std::pow(Real(1) - std::fabs(dot(half_vector, dir_out)), 5) * std::fabs(n_dot_out);
+        return true;
+    }
+    if (m.kind == LJ_MAT_DISNEYBSDF) {  // disney_bsdf.inl:3-218
+        Spectrum base_color = tex3(s, m, 0, vertex);
+        Real specular_transmission = tex1(s, m, 1, vertex), metallic = tex1(s, m, 2, vertex), subsurface = tex1(s, m, 3, vertex), specular = tex1(s, m, 4, vertex);
+        Real roughness_raw = tex1(s, m, 5, vertex), specular_tint = tex1(s, m, 6, vertex), anisotropic = tex1(s, m, 7, vertex), sheen = tex1(s, m, 8, vertex);
+        Real sheen_tint = tex1(s, m, 9, vertex), clearcoat = tex1(s, m, 10, vertex);
+        Spectrum f_diffuse{0, 0, 0}, f_metal{0, 0, 0}, f_glass{0, 0, 0}, f_clearcoat{0, 0, 0}, f_sheen{0, 0, 0};
+        if (dot(vertex.geometry_normal, dir_in) >= 0 && dot(vertex.geometry_normal, dir_out) >= 0) {
+            Frame frame = frame_to_dir_in(vertex, dir_in);
+            f_diffuse = disney_diffuse_lobe(base_color, roughness_raw, subsurface, frame, dir_in, dir_out);
+            {   // metal lobe with the achromatic specular blend (disney_bsdf.inl:56-88); Fresnel without fabs, as written (:77)
+                Vector3 half_vector = normalize(dir_in + dir_out);
+                Real roughness = clampr(roughness_raw, Real(0.01), Real(1));
+                Real h_dot_out = dot(half_vector, dir_out);
+                Spectrum C_tint = color_tint(base_color);
+                Real eta = Real(1.5);
+                Real R_0 = std::pow(eta - Real(1), 2) / std::pow(eta + Real(1), 2);
+                Spectrum Ks = Vector3{1, 1, 1} * (Real(1) - specular_tint) + specular_tint * C_tint;
+                Spectrum C0 = specular * R_0 * (Real(1) - metallic) * Ks + metallic * base_color;
+                Spectrum Fm = C0 + (Vector3{1, 1, 1} - C0) * std::pow(Real(1) - h_dot_out, 5);
+                Real ax, ay; aniso_alphas(roughness, anisotropic, ax, ay);
+                Real Dm = GTR2_aniso(ax, ay, frame, half_vector);
+                Real Gin = smithG_GGX_aniso(dot(dir_in, frame.n), dot(dir_in, frame.x), dot(dir_in, frame.y), ax, ay);
+                Real Gout = smithG_GGX_aniso(dot(dir_out, frame.n), dot(dir_out, frame.x), dot(dir_out, frame.y), ax, ay);
+                f_metal = Fm * Dm * Gin * Gout / (Real(4) * std::fabs(dot(dir_in, frame.n)));
+            }
+            {   // clearcoat (disney_bsdf.inl:91-110)
+                Vector3 half_vector = normalize(dir_in + dir_out);
+                Real n_dot_h = dot(frame.n, half_vector), n_dot_in = dot(frame.n, dir_in);
+                if (n_dot_h > 0) {
+                    Real F = clearcoat_schlick_fresnel(half_vector, dir_out);
+                    Real D = compute_Dc(tex1(s, m, 11, vertex), std::pow(dot(frame.n, half_vector), 2));
+                    Real G = smith_masking_gtr2(to_local(frame, dir_in), Real(0.5)) * smith_masking_gtr2(to_local(frame, dir_out), Real(0.5));
+                    Real v = F * D * G / (Real(4) * std::fabs(n_dot_in));
+                    f_clearcoat = {v, v, v};
+                }
+            }
+            {   // sheen (disney_bsdf.inl:113-128)
+                Vector3 half_vector = normalize(dir_in + dir_out);
+                Real n_dot_out = dot(frame.n, dir_out);
+                Spectrum C_sheen = Vector3{1, 1, 1} * (Real(1) - sheen_tint) + sheen_tint * color_tint(base_color);
+                f_sheen = C_sheen * std::pow(Real(1) - std::fabs(dot(half_vector, dir_out)), 5) * std::fabs(n_dot_out);
+            }
+        }
+        f_glass = disney_glass_lobe(base_color, roughness_raw, anisotropic, m.eta, vertex, dir_in, dir_out, nullptr);  // disney_bsdf.inl:131-175
+        if (dot(vertex.geometry_normal, dir_in) < 0) { f_diffuse = f_metal = f_sheen = f_clearcoat = Spectrum{0, 0, 0}; }
+        out = (Real(1) - specular_transmission) * (Real(1) - metallic) * f_diffuse
+            + (Real(1) - metallic) * sheen * f_sheen
+            + (Real(1) - specular_transmission * (Real(1) - metallic)) * f_metal
+            + Real(0.25) * clearcoat * f_clearcoat
+            + (Real(1) - metallic) * specular_transmission * f_glass;
         return true;
     }
     return false;
@@ -621,6 +858,88 @@ bool bsdf_pdf(const OScene *s, const LjMaterial &m, const Vector3 &dir_in, const
         spec_prob *= (G * D) / (4 * n_dot_in);
         diff_prob *= n_dot_out / c_PI;
         out = spec_prob + diff_prob;
+        return true;
+    }
+
+    const bool above = !(dot(vertex.geometry_normal, dir_in) < 0 || dot(vertex.geometry_normal, dir_out) < 0);
+    if (m.kind == LJ_MAT_ROUGHDIELECTRIC) {  // roughdielectric.inl:49-88
+        bool reflect = dot(vertex.geometry_normal, dir_in) * dot(vertex.geometry_normal, dir_out) > 0;
+        Frame frame = frame_two_sided(vertex, dir_in);
+        Real eta = dot(vertex.geometry_normal, dir_in) > 0 ? m.eta : 1 / m.eta;
+        Vector3 half_vector = reflect ? normalize(dir_in + dir_out) : normalize(dir_in + dir_out * eta);
+        if (dot(half_vector, frame.n) < 0) half_vector = -half_vector;
+        Real roughness = clampr(tex1(s, m, 2, vertex), Real(0.01), Real(1));
+        Real h_dot_in = dot(half_vector, dir_in);
+        Real F = fresnel_dielectric(h_dot_in, eta);
+        Real D = GTR2(dot(half_vector, frame.n), roughness);
+        Real G_in = smith_masking_gtr2(to_local(frame, dir_in), roughness);
+        if (reflect) out = (F * D * G_in) / (4 * std::fabs(dot(frame.n, dir_in)));
+        else {
+            Real h_dot_out = dot(half_vector, dir_out);
+            Real sqrt_denom = h_dot_in + eta * h_dot_out;
+            Real dh_dout = eta * eta * h_dot_out / (sqrt_denom * sqrt_denom);
+            out = (1 - F) * D * G_in * std::fabs(dh_dout * h_dot_in / dot(frame.n, dir_in));
+        }
+        return true;
+    }
+    if (m.kind == LJ_MAT_DISNEYDIFFUSE || m.kind == LJ_MAT_DISNEYSHEEN) {  // disney_diffuse.inl:44-58, disney_sheen.inl:33-46
+        if (!above) return true;
+        out = std::fmax(dot(frame_to_dir_in(vertex, dir_in).n, dir_out), Real(0)) / c_PI;
+        return true;
+    }
+    if (m.kind == LJ_MAT_DISNEYMETAL) {  // disney_metal.inl:95-126
+        if (!above) return true;
+        Frame frame = frame_to_dir_in(vertex, dir_in);
+        Real roughness = clampr(tex1(s, m, 1, vertex), Real(0.01), Real(1)), anisotropic = tex1(s, m, 2, vertex);
+        Vector3 half_vector = normalize(dir_in + dir_out);
+        Real ax, ay; aniso_alphas(roughness, anisotropic, ax, ay);
+        Real Dm = GTR2_aniso(ax, ay, frame, half_vector);
+        Real Gin = smithG_GGX_aniso(dot(dir_in, frame.n), dot(dir_in, frame.x), dot(dir_in, frame.y), ax, ay);
+        out = Dm * Gin / (Real(4) * std::fabs(dot(dir_in, frame.n)));
+        return true;
+    }
+    if (m.kind == LJ_MAT_DISNEYGLASS) {  // disney_glass.inl:85-135
+        disney_glass_lobe(Spectrum{1, 1, 1}, tex1(s, m, 1, vertex), tex1(s, m, 2, vertex), m.eta, vertex, dir_in, dir_out, &out);
+        return true;
+    }
+    if (m.kind == LJ_MAT_DISNEYCLEARCOAT) {  // disney_clearcoat.inl:47-66
+        if (!above) return true;
+        Frame frame = frame_to_dir_in(vertex, dir_in);
+        Vector3 half_vector = normalize(dir_in + dir_out);
+        Real n_dot_h = dot(frame.n, half_vector);
+        Real D = compute_Dc(tex1(s, m, 0, vertex), std::pow(dot(frame.n, half_vector), 2));
+        out = D * std::fabs(n_dot_h) / (Real(4) * std::fabs(dot(half_vector, dir_out)));
+        return true;
+    }
+    if (m.kind == LJ_MAT_DISNEYBSDF) {  // disney_bsdf.inl:220-372
+        bool reflect = dot(vertex.geometry_normal, dir_in) * dot(vertex.geometry_normal, dir_out) > 0;
+        Real specular_transmission = tex1(s, m, 1, vertex), metallic = tex1(s, m, 2, vertex), anisotropic = tex1(s, m, 7, vertex), clearcoat = tex1(s, m, 10, vertex);
+        Real diffuse_weight = (Real(1) - metallic) * (Real(1) - specular_transmission);
+        Real metal_weight = (Real(1) - specular_transmission * (Real(1) - metallic));
+        Real glass_weight = (Real(1) - metallic) * specular_transmission;
+        Real clearcoat_weight = Real(0.25) * clearcoat;
+        if (dot(vertex.geometry_normal, dir_in) < 0) {
+            diffuse_weight = metal_weight = clearcoat_weight = 0;
+            if (glass_weight > 0) glass_weight = 1; else return true;
+        }
+        Real weight_total = diffuse_weight + metal_weight + glass_weight + clearcoat_weight;
+        diffuse_weight /= weight_total; metal_weight /= weight_total; glass_weight /= weight_total; clearcoat_weight /= weight_total;
+        Frame frame = frame_to_dir_in(vertex, dir_in);
+        Real diffuse_pdf = std::fmax(dot(frame.n, dir_out), Real(0)) / c_PI;
+        Vector3 half_vector = normalize(dir_in + dir_out);
+        Real roughness_raw = tex1(s, m, 5, vertex);
+        Real roughness = clampr(roughness_raw, Real(0.01), Real(1));
+        Real ax, ay; aniso_alphas(roughness, anisotropic, ax, ay);
+        Real Dm = GTR2_aniso(ax, ay, frame, half_vector);
+        Real Gin = smithG_GGX_aniso(dot(dir_in, frame.n), dot(dir_in, frame.x), dot(dir_in, frame.y), ax, ay);
+        Real metal_pdf = Dm * Gin / (Real(4) * std::fabs(dot(dir_in, frame.n)));
+        Real n_dot_h = dot(frame.n, half_vector);
+        Real Dc = compute_Dc(tex1(s, m, 11, vertex), std::pow(dot(frame.n, half_vector), 2));
+        Real clearcoat_pdf = Dc * std::fabs(n_dot_h) / (Real(4) * std::fabs(dot(half_vector, dir_out)));
+        Real glass_pdf = 0;
+        disney_glass_lobe(Spectrum{1, 1, 1}, roughness_raw, anisotropic, m.eta, vertex, dir_in, dir_out, &glass_pdf);
+        if (reflect) out = diffuse_weight * diffuse_pdf + metal_weight * metal_pdf + clearcoat_weight * clearcoat_pdf + glass_weight * glass_pdf;
+        else out = glass_weight * glass_pdf;
         return true;
     }
     return false;
@@ -655,6 +974,90 @@ bool bsdf_sample(const OScene *s, const LjMaterial &m, const Vector3 &dir_in, co
             rec = {reflected, Real(0), roughness};
         } else rec = {to_world(frame, sample_cos_hemisphere(rnd_uv)), Real(0), Real(1)};
         valid = true;
+        return true;
+    }
+
+    if (m.kind == LJ_MAT_ROUGHDIELECTRIC) {  // roughdielectric.inl:90-177
+        Real eta = dot(vertex.geometry_normal, dir_in) > 0 ? m.eta : 1 / m.eta;
+        Frame frame = frame_two_sided(vertex, dir_in);
+        Real roughness = clampr(tex1(s, m, 2, vertex), Real(0.01), Real(1));
+        Real alpha = roughness * roughness;
+        Vector3 half_vector = to_world(frame, sample_visible_normals(to_local(frame, dir_in), alpha, rnd_uv));
+        valid = sample_dielectric_tail(dir_in, half_vector, frame, eta, roughness, rnd_w, rec);
+        return true;
+    }
+    if (m.kind == LJ_MAT_DISNEYDIFFUSE || m.kind == LJ_MAT_DISNEYSHEEN) {  // disney_diffuse.inl:60-76, disney_sheen.inl:48-62
+        if (dot(vertex.geometry_normal, dir_in) < 0) return true;
+        rec = {to_world(frame_to_dir_in(vertex, dir_in), sample_cos_hemisphere(rnd_uv)), Real(0), Real(1)};
+        valid = true;
+        return true;
+    }
+    if (m.kind == LJ_MAT_DISNEYMETAL) {  // disney_metal.inl:128-162
+        if (dot(vertex.geometry_normal, dir_in) < 0) return true;
+        Frame frame = frame_to_dir_in(vertex, dir_in);
+        Real roughness = clampr(tex1(s, m, 1, vertex), Real(0.01), Real(1)), anisotropic = tex1(s, m, 2, vertex);
+        Real ax, ay; aniso_alphas(roughness, anisotropic, ax, ay);
+        Vector3 half_vector = to_world(frame, sample_visible_normals_aniso(to_local(frame, dir_in), ax, ay, rnd_uv));
+        rec = {normalize(-dir_in + 2 * dot(dir_in, half_vector) * half_vector), Real(0), roughness};
+        valid = true;
+        return true;
+    }
+    if (m.kind == LJ_MAT_DISNEYGLASS) {  // disney_glass.inl:137-205
+        Frame frame = frame_two_sided(vertex, dir_in);
+        Real eta = dot(vertex.geometry_normal, dir_in) > 0 ? m.eta : 1 / m.eta;
+        Real anisotropic = tex1(s, m, 2, vertex), roughness = clampr(tex1(s, m, 1, vertex), Real(0.01), Real(1));
+        Real ax, ay; aniso_alphas(roughness, anisotropic, ax, ay);
+        Vector3 half_vector = to_world(frame, sample_visible_normals_aniso(to_local(frame, dir_in), ax, ay, rnd_uv));
+        valid = sample_dielectric_tail(dir_in, half_vector, frame, eta, roughness, rnd_w, rec);
+        return true;
+    }
+    if (m.kind == LJ_MAT_DISNEYCLEARCOAT) {  // disney_clearcoat.inl:68-106
+        if (dot(vertex.geometry_normal, dir_in) < 0) return true;
+        Frame frame = frame_to_dir_in(vertex, dir_in);
+        Vector3 half_vector = to_world(frame, sample_clearcoat_half(tex1(s, m, 0, vertex), rnd_uv));
+        rec = {normalize(-dir_in + 2 * dot(dir_in, half_vector) * half_vector), Real(0), Real(1)};
+        valid = true;
+        return true;
+    }
+    if (m.kind == LJ_MAT_DISNEYBSDF) {  // disney_bsdf.inl:374-572
+        Real specular_transmission = tex1(s, m, 1, vertex), metallic = tex1(s, m, 2, vertex), anisotropic = tex1(s, m, 7, vertex);
+        Real clearcoat = tex1(s, m, 10, vertex), clearcoat_gloss = tex1(s, m, 11, vertex);
+        Real eta = dot(vertex.geometry_normal, dir_in) > 0 ? m.eta : 1 / m.eta;
+        Real diffuse_weight = (Real(1) - metallic) * (Real(1) - specular_transmission);
+        Real metal_weight = (Real(1) - specular_transmission * (Real(1) - metallic));
+        Real glass_weight = (Real(1) - metallic) * specular_transmission;
+        Real clearcoat_weight = Real(0.25) * clearcoat;
+        if (dot(vertex.geometry_normal, dir_in) < 0) {
+            diffuse_weight = metal_weight = clearcoat_weight = 0;
+            if (glass_weight > 0) glass_weight = 1;
+            else { rec = {Vector3{0, 0, 0}, Real(0), Real(1)}; valid = true; return true; }  // a zero-direction record, NOT nullopt (:418-420)
+        }
+        Real weight_total = diffuse_weight + metal_weight + glass_weight + clearcoat_weight;
+        diffuse_weight /= weight_total; metal_weight /= weight_total; glass_weight /= weight_total; clearcoat_weight /= weight_total;
+        Real rand = rnd_w;
+        if (rand < diffuse_weight) {
+            rec = {to_world(frame_to_dir_in(vertex, dir_in), sample_cos_hemisphere(rnd_uv)), Real(0), Real(1)};
+            valid = true;
+        } else if (rand < diffuse_weight + metal_weight) {
+            Frame frame = frame_to_dir_in(vertex, dir_in);
+            Real roughness = clampr(tex1(s, m, 5, vertex), Real(0.01), Real(1));
+            Real ax, ay; aniso_alphas(roughness, anisotropic, ax, ay);
+            Vector3 half_vector = to_world(frame, sample_visible_normals_aniso(to_local(frame, dir_in), ax, ay, rnd_uv));
+            rec = {normalize(-dir_in + 2 * dot(dir_in, half_vector) * half_vector), Real(0), roughness};
+            valid = true;
+        } else if (rand < diffuse_weight + metal_weight + glass_weight) {
+            Frame frame = frame_two_sided(vertex, dir_in);
+            Real roughness = clampr(tex1(s, m, 5, vertex), Real(0.01), Real(1));
+            Real ax, ay; aniso_alphas(roughness, anisotropic, ax, ay);
+            Vector3 half_vector = to_world(frame, sample_visible_normals_aniso(to_local(frame, dir_in), ax, ay, rnd_uv));
+            Real rand_new = (rand - (diffuse_weight + metal_weight)) / glass_weight;
+            valid = sample_dielectric_tail(dir_in, half_vector, frame, eta, roughness, rand_new, rec);
+        } else {
+            Frame frame = frame_to_dir_in(vertex, dir_in);
+            Vector3 half_vector = to_world(frame, sample_clearcoat_half(clearcoat_gloss, rnd_uv));
+            rec = {normalize(-dir_in + 2 * dot(dir_in, half_vector) * half_vector), Real(0), Real(1)};
+            valid = true;
+        }
         return true;
     }
     return false;
@@ -1117,13 +1520,13 @@ void oracle_make_vertex(void *sv, const double *org, const double *dir, double r
     if (emission3 && s->shapes[shape_id].area_light_id >= 0) { Spectrum L = vertex_emission(*s, vx, -ray.dir); for (int k = 0; k < 3; k++) emission3[k] = L[k]; }
 }
 // returns 0 ok, 1 material kind not restated yet
-int oracle_bsdf(void *sv, const LjMaterial *m, const double *vertex22, const double *dir_in, const double *dir_out, const double *rnd_uv, double rnd_w,
+int oracle_bsdf(void *sv, const LjMaterial *m, const double *vertex22, const double *dir_in, const double *dir_out, const double *rnd_uv, double rnd_w, int to_view,
                 double *eval3, double *pdf, int *sample_valid, double *sample_dir3, double *sample_eta, double *sample_roughness) {
     OScene *s = (OScene *)sv;
     PathVertex vx = unpack_vertex(vertex22);
     Vector3 di{dir_in[0], dir_in[1], dir_in[2]}, dout{dir_out[0], dir_out[1], dir_out[2]};
     Spectrum f; Real p; bool valid; BSDFSampleRecord rec{};
-    if (!bsdf_eval(s, *m, di, dout, vx, f)) return 1;
+    if (!bsdf_eval(s, *m, di, dout, vx, f, to_view != 0)) return 1;
     bsdf_pdf(s, *m, di, dout, vx, p);
     bsdf_sample(s, *m, di, vx, Vector2{rnd_uv[0], rnd_uv[1]}, rnd_w, valid, rec);
     for (int k = 0; k < 3; k++) { eval3[k] = f[k]; sample_dir3[k] = valid ? rec.dir_out[k] : 0; }

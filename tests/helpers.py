@@ -113,12 +113,12 @@ class Oracle:
                                     C.c_int(prim_id), C.c_float(t), C.c_float(u), C.c_float(v), dptr(darr(Ng)), dptr(out), C.byref(mid), dptr(em))
         return out, mid.value, em
 
-    def bsdf(self, material, vertex22, dir_in, dir_out, rnd_uv, rnd_w):
+    def bsdf(self, material, vertex22, dir_in, dir_out, rnd_uv, rnd_w, to_view=0):
         ev, sd = np.zeros(3), np.zeros(3)
         pdf, eta, rough = C.c_double(), C.c_double(), C.c_double()
         valid = C.c_int()
         rc = self.lib.oracle_bsdf(self.h, C.byref(material), dptr(darr(vertex22)), dptr(darr(dir_in)), dptr(darr(dir_out)), dptr(darr(rnd_uv)),
-                                  C.c_double(rnd_w), dptr(ev), C.byref(pdf), C.byref(valid), dptr(sd), C.byref(eta), C.byref(rough))
+                                  C.c_double(rnd_w), C.c_int(to_view), dptr(ev), C.byref(pdf), C.byref(valid), dptr(sd), C.byref(eta), C.byref(rough))
         return rc, ev, pdf.value, valid.value, sd, eta.value, rough.value
 
     def intersect(self, rays):
@@ -224,3 +224,40 @@ def random_rays(hs, n, seed, oracle=None):
     d = rng.normal(size=(n, 3))
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     return lj._rays_array(org, d, 0.0, np.inf)
+
+
+def material_struct(m):
+    """material dict (the layout of tests/golden/materials.json) -> LjMaterial"""
+    out = _abi.LjMaterial()
+    out.kind = _abi.MATERIAL_KINDS.index(m["kind"])
+    slots = _abi.MATERIAL_SLOTS[m["kind"]]
+    out.n_tex = len(slots)
+    out.eta = m.get("eta", 0.0)
+    tk = {"constant": 0, "image": 1, "checkerboard": 2}
+    for i, sname in enumerate(slots):
+        t = m[sname]
+        tex = out.tex[i]
+        tex.kind = tk[t["kind"]]
+        tex.texture_id = t.get("texture_id", -1)
+        v = t.get("value", t.get("color0", 0.0))
+        v = [v] * 3 if not isinstance(v, list) else v
+        c1 = t.get("color1", 0.0)
+        c1 = [c1] * 3 if not isinstance(c1, list) else c1
+        for k in range(3):
+            tex.value[k], tex.color1[k] = v[k], c1[k]
+        tex.uscale, tex.vscale = t.get("uscale", 1.0), t.get("vscale", 1.0)
+        tex.uoffset, tex.voffset = t.get("uoffset", 0.0), t.get("voffset", 0.0)
+    return out
+
+
+
+
+def const(v):
+    return {"kind": "constant", "value": v}
+
+
+def set_material(hs, index, mdict):
+    """Overwrite material `index` of a parsed scene (the description is plain memory owned by the HostScene)."""
+    import ctypes
+    m = material_struct(mdict)
+    ctypes.memmove(ctypes.addressof(hs.desc.materials[index]), ctypes.addressof(m), ctypes.sizeof(m))

@@ -1,0 +1,46 @@
+"""The seven remaining Material alternatives (material.h:102-110) inside the integrator: cbox with the two boxes (and, for
+one case, the floor) re-materialised, device shading code (host build, float) against the oracle (double) path by path.
+Bars as in test_twin_parity.py; transmissive materials get a wider diverged-sample allowance because a refraction /
+reflection choice flips whole sub-paths."""
+import numpy as np
+import pytest
+
+import lajolla_public_amd as lj
+from helpers import Oracle, Twin, const, scene_path, set_material
+
+W = [0.8, 0.75, 0.7]
+MATERIALS = {
+    "roughdielectric": dict(kind="roughdielectric", specular_reflectance=const([1, 1, 1]), specular_transmittance=const([0.9, 0.95, 1.0]), roughness=const(0.2), eta=1.5),
+    "disneydiffuse": dict(kind="disneydiffuse", base_color=const(W), roughness=const(0.6), subsurface=const(0.4)),
+    "disneymetal": dict(kind="disneymetal", base_color=const([0.9, 0.6, 0.3]), roughness=const(0.3), anisotropic=const(0.5)),
+    "disneyglass": dict(kind="disneyglass", base_color=const([0.9, 0.9, 0.95]), roughness=const(0.15), anisotropic=const(0.3), eta=1.45),
+    "disneyclearcoat": dict(kind="disneyclearcoat", clearcoat_gloss=const(0.7)),
+    "disneysheen": dict(kind="disneysheen", base_color=const(W), sheen_tint=const(0.5)),
+    "disneybsdf": dict(kind="disneybsdf", base_color=const([0.82, 0.67, 0.16]), specular_transmission=const(0.5), metallic=const(0.5), subsurface=const(0.5),
+                       specular=const(0.5), roughness=const(0.1), specular_tint=const(0.5), anisotropic=const(0.5), sheen=const(0.5), sheen_tint=const(0.5),
+                       clearcoat=const(0.5), clearcoat_gloss=const(0.5), eta=1.5),   # the parameter set of scenes/disney_bsdf_test/disney_bsdf.xml
+    "disneybsdf_opaque": dict(kind="disneybsdf", base_color={"kind": "checkerboard", "color0": [0.8, 0.3, 0.2], "color1": [0.2, 0.3, 0.8], "uscale": 4, "vscale": 4, "uoffset": 0, "voffset": 0},
+                              specular_transmission=const(0.0), metallic=const(0.2), subsurface=const(0.3), specular=const(0.8), roughness=const(0.4),
+                              specular_tint=const(0.2), anisotropic=const(0.0), sheen=const(1.0), sheen_tint=const(0.3), clearcoat=const(1.0), clearcoat_gloss=const(0.9), eta=1.5),
+}
+DIVERGED = {"roughdielectric": 0.08, "disneyglass": 0.08, "disneybsdf": 0.06}
+
+
+@pytest.mark.parametrize("name", sorted(MATERIALS))
+def test_material_in_the_integrator(name):
+    hs = lj.parse_scene(scene_path("cbox"))
+    set_material(hs, 0, MATERIALS[name])          # "box": both boxes
+    if name == "disneybsdf_opaque":
+        set_material(hs, 1, MATERIALS[name])      # "white": floor, ceiling, back wall
+    o, tw = Oracle(hs), Twin(hs)
+    crop, spp = (176, 232, 240, 296), 8           # straddles the tall box, its shadow and the floor
+    rc, _, ps, st = o.render(spp=spp, rng_mode=0, crop=crop, per_sample=True)
+    assert rc == 0
+    pt, bounces = tw.render_samples(crop, spp)
+    assert np.isfinite(pt).all()
+    rel = np.abs(pt - ps).max(axis=-1) / np.maximum(np.abs(ps).max(axis=-1), 1e-3)
+    assert np.median(rel) < 5e-6, np.median(rel)
+    assert (rel > 1e-3).mean() < DIVERGED.get(name, 0.03), (rel > 1e-3).mean()
+    # firefly-robust mean: a handful of diverged caustic paths (values 50-80 against a typical 0.4) would otherwise decide it
+    assert abs(np.minimum(pt, 4.0).mean() / np.minimum(ps, 4.0).mean() - 1) < 3e-3
+    assert abs(bounces / st.bounces - 1) < 2e-2
