@@ -13,17 +13,20 @@ LJ_HD f3 texel(const DScene &sc, const DImage &img, int level, int x, int y) {
     const float *p = sc.texels + lv.offset + ((int64_t)y * lv.w + x) * img.channels;
     return img.channels >= 3 ? mk3(p[0], p[1], p[2]) : mk3(p[0], p[0], p[0]);
 }
-LJ_HD f3 mip_lookup_level(const DScene &sc, const DImage &img, float u, float v, int level) {
+// Texture coordinates are carried in double: tiled uvs reach tens of units and a 1000-texel image needs ~1e-8 relative
+// precision in the fractional part for the bilinear weights to agree with the reference's double arithmetic; MI355X
+// runs fp64 at half the fp32 rate, and only the addressing is double — texel blending stays float.
+LJ_HD f3 mip_lookup_level(const DScene &sc, const DImage &img, double u, double v, int level) {
     const int W = img.lv[level].w, H = img.lv[level].h;
-    u = u * W - 0.5f; v = v * H - 0.5f;
+    u = u * W - 0.5; v = v * H - 0.5;
     int ufi = moduloi((int)u, W), vfi = moduloi((int)v, H);
     int uci = moduloi(ufi + 1, W), vci = moduloi(vfi + 1, H);
-    float uo = u - ufi, vo = v - vfi;
+    float uo = (float)(u - ufi), vo = (float)(v - vfi);
     f3 ff = texel(sc, img, level, ufi, vfi), fc = texel(sc, img, level, ufi, vci);
     f3 cf = texel(sc, img, level, uci, vfi), cc = texel(sc, img, level, uci, vci);
     return ff * ((1 - uo) * (1 - vo)) + fc * ((1 - uo) * vo) + cf * (uo * (1 - vo)) + cc * (uo * vo);
 }
-LJ_HD f3 mip_lookup(const DScene &sc, const DImage &img, float u, float v, float level) {
+LJ_HD f3 mip_lookup(const DScene &sc, const DImage &img, double u, double v, float level) {
     if (level <= 0.0f) return mip_lookup_level(sc, img, u, v, 0);
     if (level < (float)(img.levels - 1)) {
         int fl = (int)floorf(level); fl = fl < 0 ? 0 : (fl > img.levels - 1 ? img.levels - 1 : fl);
@@ -33,9 +36,10 @@ LJ_HD f3 mip_lookup(const DScene &sc, const DImage &img, float u, float v, float
     }
     return mip_lookup_level(sc, img, u, v, img.levels - 1);
 }
-LJ_HD f3 eval_texture(const DScene &sc, const DTexture &t, bool spectrum, float u, float v, float footprint) {
+LJ_HD double modulod(double a, double b) { double r = fmod(a, b); return (r < 0.0) ? r + b : r; }
+LJ_HD f3 eval_texture(const DScene &sc, const DTexture &t, bool spectrum, double u, double v, float footprint) {
     if (t.kind == 0) return ld3(t.value);
-    float lu = modulof(u * t.uscale + t.uoffset, 1.0f), lv = modulof(v * t.vscale + t.voffset, 1.0f);
+    double lu = modulod(u * (double)t.uscale + (double)t.uoffset, 1.0), lv = modulod(v * (double)t.vscale + (double)t.voffset, 1.0);
     if (t.kind == 1) {
         const DImage &img = spectrum ? sc.images3[t.texture_id] : sc.images1[t.texture_id];
         float scaled = (float)(img.lv[0].w > img.lv[0].h ? img.lv[0].w : img.lv[0].h) * fmaxf(t.uscale, t.vscale) * footprint;
@@ -96,7 +100,7 @@ LJ_HD int sample_cdf(const float *cdf, int n, float u) {
 struct DVertex {
     f3 position, gn;
     Frame3 frame;
-    float u, v;              // texture uv
+    double u, v;             // texture uv (double: see mip_lookup_level)
     float uv_screen_size;
     int32_t material_id, light_id, gprim;
     bool is_sphere;
@@ -112,8 +116,11 @@ LJ_HD DVertex build_vertex(const DScene &sc, f3 org, f3 dir, float t, float bu, 
     float inv_uv_size;
     if (!vx.is_sphere) {  // triangle_mesh.inl:65-157
         float b0 = 1.0f - bu - bv;
-        vx.u = b0 * ps.uv0[0] + bu * ps.uv1[0] + bv * ps.uv2[0];
-        vx.v = b0 * ps.uv0[1] + bu * ps.uv1[1] + bv * ps.uv2[1];
+        {   // (1 - s - t) uv0 + s uv1 + t uv2 with s, t the float barycentrics widened, as the reference does (triangle_mesh.inl:81-83)
+            const double s_ = bu, t_ = bv, b0d = 1.0 - s_ - t_;
+            vx.u = b0d * ps.uv0[0] + s_ * ps.uv1[0] + t_ * ps.uv2[0];
+            vx.v = b0d * ps.uv0[1] + s_ * ps.uv1[1] + t_ * ps.uv2[1];
+        }
         f3 gn = ld3(ps.gn), sn = gn;
         if (ps.flags & 2) sn = normalize(ld3(ps.n0) * b0 + ld3(ps.n1) * bu + ld3(ps.n2) * bv);
         f3 dpdu = ld3(ps.dpdu);
@@ -176,9 +183,11 @@ LJ_HD LightSample sample_point_on_light(const DScene &sc, const DLight &L, f3 re
                 float cos_elevation = 1.0f - omc;
                 float sin_sq = omc * (2.0f - omc);               // 1 - cos^2, stable
                 float azimuth = u1 * kTwoPi;
-                float dc = sqrtf(dist_sq);
-                float ds = dc * cos_elevation - sqrtf(fmaxf(0.0f, r * r - dist_sq * sin_sq));
-                float cos_alpha = (dist_sq + r * r - ds * ds) / (2.0f * dc * r);
+                // The reference (pbrt-v3 form, sphere.inl:186-193) gets cos_alpha from dc^2 + r^2 - ds^2, which cancels
+                // catastrophically in float for a small, distant sphere.  This is the same quantity in the
+                // cancellation-free form:  cos_alpha = sin^2(theta)/sin(theta_max) + cos(theta) sqrt(1 - sin^2(theta)/sin^2(theta_max)).
+                float sin_max_sq = r * r / dist_sq, sin_max = sqrtf(sin_max_sq);
+                float cos_alpha = sin_sq / sin_max + cos_elevation * sqrtf(fmaxf(0.0f, 1.0f - sin_sq / sin_max_sq));
                 float sin_alpha = sqrtf(fmaxf(0.0f, 1.0f - cos_alpha * cos_alpha));
                 f3 n = -to_world(frame, mk3(sin_alpha * cosf(azimuth), sin_alpha * sinf(azimuth), cos_alpha));
                 ls.position = n * r + center; ls.normal = n;

@@ -2,19 +2,21 @@
 // delegates to stb_image and tinyexr).  Returned data is float, row-major, y=0 at the top.
 //
 // Decoders implemented here, from the format specifications (no third-party code):
-//   .pfm   portable float map (colour "PF" / grey "Pf"), bottom-up or top-down by the sign of the scale
-// LDR formats are gamma-decoded the way stb's stbi_loadf does it: pow(v/255, 2.2) (stb_image.h:1553,1849),
-// which is what the reference's ImageTextures hold.
-//
-// JPEG and OpenEXR (needed by scenes/sponza and scenes/disney_bsdf_test) are the next front-end row
-// (SURVEY §8f-2); until they land, loading such a file fails loudly with LJ_ERR_UNSUPPORTED.
+//   .pfm          portable float map (colour "PF" / grey "Pf"), bottom-up, endianness by the sign of the scale
+//   .jpg / .jpeg  baseline JPEG (jpeg_decode.cpp), then the LDR -> linear conversion stb's stbi_loadf applies:
+//                 (float) pow(v / 255.0f, 2.2f)  (stb_image.h:1553,1849) — what the reference's ImageTextures hold.
+// OpenEXR is not decoded yet: the one EXR the BASELINE scenes use (matpreview/envmap.exr) ships in this
+// repo as a PFM converted with the reference's own decoder (oracle/convert_assets.cpp); other formats fail loudly.
 #include "host_scene.h"
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <fstream>
 #include <sstream>
 
 namespace lj {
+
+std::vector<uint8_t> decode_jpeg_rgb8(const std::vector<uint8_t> &file, int &width, int &height, const std::string &name);
 
 namespace {
 
@@ -65,6 +67,22 @@ HostImage convert_channels(const HostImage &src, int channels) {
 HostImage read_image(const std::string &filename, int channels) {
     std::string ext = ext_of(filename);
     if (ext == ".pfm") return convert_channels(read_pfm(filename), channels);
+    if (ext == ".jpg" || ext == ".jpeg") {
+        std::ifstream f(filename, std::ios::binary);
+        if (!f) throw LjError(LJ_ERR_IO, "cannot open image: " + filename);
+        std::vector<uint8_t> bytes((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+        int w = 0, h = 0;
+        std::vector<uint8_t> rgb = decode_jpeg_rgb8(bytes, w, h, filename);
+        HostImage img; img.width = w; img.height = h; img.channels = channels == 1 ? 1 : 3;
+        img.data.resize((size_t)w * h * img.channels);
+        // stbi_loadf(..., req_comp): 3 -> RGB; 1 -> luma (77 R + 150 G + 29 B) >> 8 of the decoded RGB (stb_image.h stbi__compute_y)
+        const float gamma = 2.2f;
+        for (size_t i = 0; i < (size_t)w * h; i++) {
+            if (img.channels == 3) { for (int c = 0; c < 3; c++) img.data[3 * i + c] = (float)std::pow((double)(rgb[3 * i + c] / 255.0f), (double)gamma); }
+            else { uint8_t y = (uint8_t)((rgb[3 * i] * 77 + rgb[3 * i + 1] * 150 + 29 * rgb[3 * i + 2]) >> 8); img.data[i] = (float)std::pow((double)(y / 255.0f), (double)gamma); }
+        }
+        return img;
+    }
     throw LjError(LJ_ERR_UNSUPPORTED, "image format '" + ext + "' is not decoded by this build yet (SURVEY §8f-2): " + filename);
 }
 

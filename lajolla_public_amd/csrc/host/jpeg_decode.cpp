@@ -1,0 +1,280 @@
+// Baseline JPEG (ITU-T T.81, sequential DCT, Huffman, 8-bit) decoder for texture input.
+//
+// The reference loads LDR textures through stb_image (image.cpp:44,96), so texel values depend on three choices the
+// JPEG standard leaves to the decoder.  We make the same ones so that the decoded texels are bit-identical to what
+// the reference's TexturePool holds (checked against tests/golden/scene_sponza.json):
+//   * the 8x8 inverse DCT is the 13-bit "slow integer" (Loeffler-Ligtenberg-Moschytz) transform with 12-bit constants,
+//     two passes, 2 extra bits kept between them, +128 level shift folded into the final rounding;
+//   * 2x2 chroma upsampling uses the triangle filter  (3*near + far) per axis: (3*t_i + t_{i±1} + 8) >> 4;
+//   * YCbCr -> RGB in 20-bit fixed point with the BT.601 constants quantised to 12 bits.
+// Progressive / arithmetic-coded / 12-bit files are rejected with LJ_ERR_UNSUPPORTED.
+#include "host_scene.h"
+#include <cstring>
+#include <fstream>
+
+namespace lj {
+
+namespace {
+
+struct Huff {
+    // canonical Huffman table (T.81 Annex C): codes of length l are consecutive, starting at first_code[l]
+    uint8_t nsym[17]; uint8_t sym[256];
+    int first_code[18], first_index[18];
+    void build() {
+        int code = 0, idx = 0;
+        for (int l = 1; l <= 16; l++) { first_code[l] = code; first_index[l] = idx; code = (code + nsym[l]) << 1; idx += nsym[l]; }
+    }
+};
+
+struct Component { int id, h, v, tq, td, ta; int w2, h2; std::vector<uint8_t> data; int dc_pred; };
+
+struct BitReader {
+    const uint8_t *p, *end; uint32_t buf = 0; int nbits = 0; bool hit_marker = false;
+    void fill() {
+        while (nbits <= 24) {
+            int b = 0;
+            if (!hit_marker && p < end) {
+                b = *p++;
+                if (b == 0xFF) {
+                    int c = p < end ? *p : 0;
+                    if (c == 0) p++;            // stuffed zero
+                    else { hit_marker = true; p--; b = 0; }  // a marker: feed zeros from here on
+                }
+            }
+            buf |= (uint32_t)b << (24 - nbits); nbits += 8;
+        }
+    }
+    int bit() { if (nbits < 1) fill(); int r = buf >> 31; buf <<= 1; nbits--; return r; }
+    int bits(int n) { if (n == 0) return 0; if (nbits < n) fill(); int r = buf >> (32 - n); buf <<= n; nbits -= n; return r; }
+    void reset() { buf = 0; nbits = 0; hit_marker = false; }
+};
+
+int decode_symbol(BitReader &br, const Huff &h) {
+    int code = 0;
+    for (int l = 1; l <= 16; l++) {
+        code = (code << 1) | br.bit();
+        if (h.nsym[l] && code - h.first_code[l] < h.nsym[l] && code >= h.first_code[l]) return h.sym[h.first_index[l] + code - h.first_code[l]];
+    }
+    throw LjError(LJ_ERR_PARSE, "corrupt JPEG: bad Huffman code");
+}
+inline int extend(int v, int n) { return (n && v < (1 << (n - 1))) ? v - (1 << n) + 1 : v; }  // T.81 F.2.2.1
+
+inline uint8_t clamp8(int x) { return (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x)); }
+inline int f2f(double x) { return (int)(x * 4096 + 0.5); }
+
+// one 1-D pass of the slow-integer IDCT on s0..s7; results are x0..x3 (even part) and t0..t3 (odd part), scaled by 2^12
+#define LJ_IDCT_1D(s0, s1, s2, s3, s4, s5, s6, s7)                                                 \
+    int t0, t1, t2, t3, p1, p2, p3, p4, p5, x0, x1, x2, x3;                                       \
+    p2 = s2; p3 = s6;                                                                              \
+    p1 = (p2 + p3) * f2f(0.5411961f); t2 = p1 + p3 * f2f(-1.847759065f); t3 = p1 + p2 * f2f(0.765366865f); \
+    p2 = s0; p3 = s4;                                                                              \
+    t0 = (p2 + p3) * 4096; t1 = (p2 - p3) * 4096;                                                  \
+    x0 = t0 + t3; x3 = t0 - t3; x1 = t1 + t2; x2 = t1 - t2;                                        \
+    t0 = s7; t1 = s5; t2 = s3; t3 = s1;                                                            \
+    p3 = t0 + t2; p4 = t1 + t3; p1 = t0 + t3; p2 = t1 + t2;                                        \
+    p5 = (p3 + p4) * f2f(1.175875602f);                                                            \
+    t0 = t0 * f2f(0.298631336f); t1 = t1 * f2f(2.053119869f); t2 = t2 * f2f(3.072711026f); t3 = t3 * f2f(1.501321110f); \
+    p1 = p5 + p1 * f2f(-0.899976223f); p2 = p5 + p2 * f2f(-2.562915447f);                          \
+    p3 = p3 * f2f(-1.961570560f); p4 = p4 * f2f(-0.390180644f);                                    \
+    t3 += p1 + p4; t2 += p2 + p3; t1 += p2 + p4; t0 += p1 + p3;
+
+void idct_block(uint8_t *out, int stride, const short d[64]) {
+    int val[64];
+    for (int i = 0; i < 8; i++) {  // columns
+        const short *c = d + i; int *v = val + i;
+        LJ_IDCT_1D(c[0], c[8], c[16], c[24], c[32], c[40], c[48], c[56])
+        x0 += 512; x1 += 512; x2 += 512; x3 += 512;  // keep 2 extra bits
+        v[0] = (x0 + t3) >> 10; v[56] = (x0 - t3) >> 10; v[8] = (x1 + t2) >> 10; v[48] = (x1 - t2) >> 10;
+        v[16] = (x2 + t1) >> 10; v[40] = (x2 - t1) >> 10; v[24] = (x3 + t0) >> 10; v[32] = (x3 - t0) >> 10;
+    }
+    for (int i = 0; i < 8; i++) {  // rows; 2^12 * 2^2 * 2^3 = 2^17 to remove, round, and level-shift by +128
+        const int *v = val + 8 * i; uint8_t *o = out + (size_t)stride * i;
+        LJ_IDCT_1D(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7])
+        const int bias = 65536 + (128 << 17);
+        x0 += bias; x1 += bias; x2 += bias; x3 += bias;
+        o[0] = clamp8((x0 + t3) >> 17); o[7] = clamp8((x0 - t3) >> 17); o[1] = clamp8((x1 + t2) >> 17); o[6] = clamp8((x1 - t2) >> 17);
+        o[2] = clamp8((x2 + t1) >> 17); o[5] = clamp8((x2 - t1) >> 17); o[3] = clamp8((x3 + t0) >> 17); o[4] = clamp8((x3 - t0) >> 17);
+    }
+}
+
+const uint8_t kZigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+                             35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+// upsample one output row of a component to full width
+void resample_row(uint8_t *out, const uint8_t *near_, const uint8_t *far_, int w_lores, int hs, int vs) {
+    if (hs == 1 && vs == 1) { memcpy(out, near_, w_lores); return; }
+    if (hs == 1 && vs == 2) { for (int i = 0; i < w_lores; i++) out[i] = (uint8_t)((3 * near_[i] + far_[i] + 2) >> 2); return; }
+    if (hs == 2 && vs == 1) {
+        const uint8_t *in = near_;
+        if (w_lores == 1) { out[0] = out[1] = in[0]; return; }
+        out[0] = in[0]; out[1] = (uint8_t)((in[0] * 3 + in[1] + 2) >> 2);
+        int i;
+        for (i = 1; i < w_lores - 1; i++) { int n = 3 * in[i] + 2; out[i * 2] = (uint8_t)((n + in[i - 1]) >> 2); out[i * 2 + 1] = (uint8_t)((n + in[i + 1]) >> 2); }
+        out[i * 2] = (uint8_t)((in[w_lores - 2] * 3 + in[w_lores - 1] + 2) >> 2); out[i * 2 + 1] = in[w_lores - 1];
+        return;
+    }
+    if (hs == 2 && vs == 2) {
+        if (w_lores == 1) { out[0] = out[1] = (uint8_t)((3 * near_[0] + far_[0] + 2) >> 2); return; }
+        int t1 = 3 * near_[0] + far_[0], t0;
+        out[0] = (uint8_t)((t1 + 2) >> 2);
+        for (int i = 1; i < w_lores; i++) {
+            t0 = t1; t1 = 3 * near_[i] + far_[i];
+            out[i * 2 - 1] = (uint8_t)((3 * t0 + t1 + 8) >> 4); out[i * 2] = (uint8_t)((3 * t1 + t0 + 8) >> 4);
+        }
+        out[w_lores * 2 - 1] = (uint8_t)((t1 + 2) >> 2);
+        return;
+    }
+    for (int i = 0; i < w_lores; i++) for (int j = 0; j < hs; j++) out[i * hs + j] = near_[i];  // other ratios: replicate
+}
+
+inline int fixed12(float x) { return ((int)(x * 4096.0f + 0.5f)) << 8; }
+
+} // namespace
+
+// returns 8-bit interleaved RGB (or grey replicated), width*height*3
+std::vector<uint8_t> decode_jpeg_rgb8(const std::vector<uint8_t> &file, int &width, int &height, const std::string &name) {
+    auto bad = [&](const char *why) -> LjError { return LjError(LJ_ERR_PARSE, std::string("JPEG ") + name + ": " + why); };
+    size_t pos = 0, n = file.size();
+    if (n < 4 || file[0] != 0xFF || file[1] != 0xD8) throw bad("not a JPEG (no SOI)");
+    pos = 2;
+    uint16_t qt[4][64]; bool have_qt[4] = {false, false, false, false};
+    Huff hdc[4], hac[4]; bool have_dc[4] = {false}, have_ac[4] = {false};
+    std::vector<Component> comp;
+    int restart_interval = 0, hmax = 1, vmax = 1;
+    bool jfif = false; int app14_transform = -1;
+    width = height = 0;
+    auto rd16 = [&](size_t p) { return (file[p] << 8) | file[p + 1]; };
+    for (;;) {
+        while (pos < n && file[pos] != 0xFF) pos++;
+        while (pos < n && file[pos] == 0xFF) pos++;
+        if (pos >= n) throw bad("unexpected end of file");
+        int m = file[pos++];
+        if (m == 0xD9) throw bad("EOI before any scan");
+        if (m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;
+        if (pos + 2 > n) throw bad("truncated segment");
+        int len = rd16(pos);
+        if (len < 2 || pos + len > n) throw bad("bad segment length");
+        size_t seg = pos + 2, seg_end = pos + len;
+        if (m == 0xDB) {  // DQT
+            while (seg < seg_end) {
+                int pq = file[seg] >> 4, tq = file[seg] & 15; seg++;
+                if (tq > 3) throw bad("bad DQT id");
+                for (int i = 0; i < 64; i++) { qt[tq][kZigzag[i]] = pq ? (uint16_t)rd16(seg) : file[seg]; seg += pq ? 2 : 1; }
+                have_qt[tq] = true;
+            }
+        } else if (m == 0xC4) {  // DHT
+            while (seg < seg_end) {
+                int tc = file[seg] >> 4, th = file[seg] & 15; seg++;
+                if (tc > 1 || th > 3) throw bad("bad DHT id");
+                Huff &h = tc ? hac[th] : hdc[th];
+                int total = 0; h.nsym[0] = 0;
+                for (int l = 1; l <= 16; l++) { h.nsym[l] = file[seg++]; total += h.nsym[l]; }
+                if (total > 256 || seg + total > seg_end) throw bad("bad DHT");
+                memcpy(h.sym, &file[seg], total); seg += total;
+                h.build(); (tc ? have_ac : have_dc)[th] = true;
+            }
+        } else if (m == 0xC0 || m == 0xC1) {  // SOF0 / SOF1: sequential Huffman
+            if (file[seg] != 8) throw LjError(LJ_ERR_UNSUPPORTED, "JPEG " + name + ": only 8-bit samples are supported");
+            height = rd16(seg + 1); width = rd16(seg + 3);
+            int nc = file[seg + 5];
+            if (width <= 0 || height <= 0 || (nc != 1 && nc != 3)) throw LjError(LJ_ERR_UNSUPPORTED, "JPEG " + name + ": unsupported component count");
+            comp.resize(nc);
+            for (int i = 0; i < nc; i++) {
+                comp[i].id = file[seg + 6 + 3 * i]; comp[i].h = file[seg + 7 + 3 * i] >> 4; comp[i].v = file[seg + 7 + 3 * i] & 15; comp[i].tq = file[seg + 8 + 3 * i];
+                if (comp[i].h < 1 || comp[i].h > 4 || comp[i].v < 1 || comp[i].v > 4 || comp[i].tq > 3) throw bad("bad SOF component");
+                hmax = std::max(hmax, comp[i].h); vmax = std::max(vmax, comp[i].v);
+            }
+        } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
+            throw LjError(LJ_ERR_UNSUPPORTED, "JPEG " + name + ": progressive / lossless / arithmetic-coded files are not supported");
+        } else if (m == 0xDD) { restart_interval = rd16(seg); }
+        else if (m == 0xE0) { if (len >= 7 && !memcmp(&file[seg], "JFIF\0", 5)) jfif = true; }
+        else if (m == 0xEE) { if (len >= 14 && !memcmp(&file[seg], "Adobe\0", 6)) app14_transform = file[seg + 11]; }
+        else if (m == 0xDA) {  // SOS: baseline files have one interleaved scan
+            if (comp.empty()) throw bad("SOS before SOF");
+            int ns = file[seg];
+            if (ns != (int)comp.size()) throw LjError(LJ_ERR_UNSUPPORTED, "JPEG " + name + ": non-interleaved scans are not supported");
+            for (int i = 0; i < ns; i++) {
+                int id = file[seg + 1 + 2 * i], tt = file[seg + 2 + 2 * i], k = -1;
+                for (int c = 0; c < (int)comp.size(); c++) if (comp[c].id == id) k = c;
+                if (k < 0) throw bad("SOS references an unknown component");
+                comp[k].td = tt >> 4; comp[k].ta = tt & 15;
+                if (comp[k].td > 3 || comp[k].ta > 3 || !have_dc[comp[k].td] || !have_ac[comp[k].ta] || !have_qt[comp[k].tq]) throw bad("scan uses an undefined table");
+            }
+            pos = seg_end;
+            break;
+        }
+        pos = seg_end;
+    }
+    // ---- entropy-coded segment
+    const int mcu_w = 8 * hmax, mcu_h = 8 * vmax;
+    const int mcux = (width + mcu_w - 1) / mcu_w, mcuy = (height + mcu_h - 1) / mcu_h;
+    for (auto &c : comp) { c.w2 = mcux * c.h * 8; c.h2 = mcuy * c.v * 8; c.data.assign((size_t)c.w2 * c.h2, 0); c.dc_pred = 0; }
+    BitReader br; br.p = &file[pos]; br.end = file.data() + n;
+    int todo = restart_interval ? restart_interval : 0x7fffffff;
+    short block[64];
+    for (int my = 0; my < mcuy; my++) for (int mx = 0; mx < mcux; mx++) {
+        for (auto &c : comp) for (int by = 0; by < c.v; by++) for (int bx = 0; bx < c.h; bx++) {
+            memset(block, 0, sizeof block);
+            int t = decode_symbol(br, hdc[c.td]);
+            if (t > 11) throw bad("bad DC magnitude");
+            int diff = t ? extend(br.bits(t), t) : 0;
+            c.dc_pred += diff;
+            block[0] = (short)(c.dc_pred * qt[c.tq][0]);
+            for (int k = 1; k < 64;) {
+                int rs = decode_symbol(br, hac[c.ta]);
+                int r = rs >> 4, s = rs & 15;
+                if (s == 0) { if (r != 15) break; k += 16; continue; }
+                k += r;
+                if (k > 63) throw bad("AC index out of range");
+                block[kZigzag[k]] = (short)(extend(br.bits(s), s) * qt[c.tq][kZigzag[k]]);
+                k++;
+            }
+            idct_block(&c.data[(size_t)(my * c.v + by) * 8 * c.w2 + (size_t)(mx * c.h + bx) * 8], c.w2, block);
+        }
+        if (--todo <= 0) {  // restart marker: realign, reset predictors
+            br.reset();
+            const uint8_t *q = br.p;
+            while (q + 1 < br.end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) q++;
+            if (q + 1 < br.end) br.p = q + 2; else br.p = br.end;
+            for (auto &c : comp) c.dc_pred = 0;
+            todo = restart_interval;
+        }
+    }
+    // ---- upsample + colour conversion, one output row at a time
+    std::vector<uint8_t> out((size_t)width * height * 3);
+    const int nc = (int)comp.size();
+    const bool is_rgb = nc == 3 && ((comp[0].id == 'R' && comp[1].id == 'G' && comp[2].id == 'B') || (app14_transform == 0 && !jfif));
+    struct Res { int hs, vs, ystep, w_lores, ypos; const uint8_t *line0, *line1; std::vector<uint8_t> buf; } res[3];
+    for (int k = 0; k < nc; k++) {
+        res[k].hs = hmax / comp[k].h; res[k].vs = vmax / comp[k].v; res[k].ystep = res[k].vs >> 1;
+        res[k].w_lores = (width + res[k].hs - 1) / res[k].hs; res[k].ypos = 0;
+        res[k].line0 = res[k].line1 = comp[k].data.data(); res[k].buf.resize((size_t)width + 8);
+    }
+    const int comp_rows[3] = {nc > 0 ? (height * comp[0].v + vmax - 1) / vmax : 0, nc > 1 ? (height * comp[1].v + vmax - 1) / vmax : 0, nc > 2 ? (height * comp[2].v + vmax - 1) / vmax : 0};
+    for (int j = 0; j < height; j++) {
+        const uint8_t *row[3];
+        for (int k = 0; k < nc; k++) {
+            Res &r = res[k];
+            bool y_bot = r.ystep >= (r.vs >> 1);
+            resample_row(r.buf.data(), y_bot ? r.line1 : r.line0, y_bot ? r.line0 : r.line1, r.w_lores, r.hs, r.vs);
+            row[k] = r.buf.data();
+            if (++r.ystep >= r.vs) { r.ystep = 0; r.line0 = r.line1; if (++r.ypos < comp_rows[k]) r.line1 += comp[k].w2; }
+        }
+        uint8_t *o = &out[(size_t)j * width * 3];
+        if (nc == 1) { for (int i = 0; i < width; i++) { o[3 * i] = o[3 * i + 1] = o[3 * i + 2] = row[0][i]; } }
+        else if (is_rgb) { for (int i = 0; i < width; i++) { o[3 * i] = row[0][i]; o[3 * i + 1] = row[1][i]; o[3 * i + 2] = row[2][i]; } }
+        else {
+            for (int i = 0; i < width; i++) {
+                int y_fixed = (row[0][i] << 20) + (1 << 19);
+                int cr = row[2][i] - 128, cb = row[1][i] - 128;
+                int r = y_fixed + cr * fixed12(1.40200f);
+                int g = y_fixed + (cr * -fixed12(0.71414f)) + ((cb * -fixed12(0.34414f)) & 0xffff0000);
+                int b = y_fixed + cb * fixed12(1.77200f);
+                o[3 * i] = clamp8(r >> 20); o[3 * i + 1] = clamp8(g >> 20); o[3 * i + 2] = clamp8(b >> 20);
+            }
+        }
+    }
+    return out;
+}
+
+} // namespace lj

@@ -58,7 +58,7 @@ def test_null_arguments_are_rejected():
     assert b"null" in lib.lj_last_error()
 
 
-@pytest.mark.parametrize("name", ["cbox", "veach_mi"])
+@pytest.mark.parametrize("name", ["cbox", "veach_mi", "disney_bsdf", "sponza"])
 def test_flattened_tables_match_reference(name):
     """The host half of Scene::Scene (scene.cpp:30-52) as the product computes it, against the reference's numbers."""
     hs = lj.parse_scene(scene_path(name))
@@ -68,19 +68,21 @@ def test_flattened_tables_match_reference(name):
     assert np.isclose(t["shadow_epsilon"], g["shadow_epsilon"], rtol=1e-12)
     assert np.allclose(t["light_pmf"], g["light_pmf"], rtol=1e-12) and np.allclose(t["light_cdf"], g["light_cdf"], rtol=1e-12)
     assert np.allclose(t["light_power"], [l["power"] for l in g["lights"]], rtol=1e-12)
-    assert t["bvh_depth"] <= 16 and t["n_nodes"] >= 1
+    assert t["bvh_depth"] <= 40 and t["n_nodes"] >= 1
 
 
-@pytest.mark.parametrize("name", ["cbox", "veach_mi"])
+@pytest.mark.parametrize("name", ["cbox", "veach_mi", "disney_bsdf", "sponza"])
 def test_bvh_traversal_equals_brute_force(name):
     """The device traversal code (host build) over the SAH BVH must return bit-identical hits to the oracle's
     exhaustive scan: closest hit = min (t, primitive id), so the result cannot depend on the tree."""
     hs = lj.parse_scene(scene_path(name))
     o = Oracle(hs)
     tw = Twin(hs)
-    rays = random_rays(hs, 100000, 7, o)
+    big = hs.desc.n_triangles > 1000
+    o.use_bvh(False)   # exhaustive scan over every primitive: the definition of the closest hit
+    rays = random_rays(hs, 3000 if big else 100000, 7, o)
     ho, ht = o.intersect(rays), tw.intersect(rays)
-    assert (ho["shape_id"] >= 0).mean() > 0.3
+    assert (ho["shape_id"] >= 0).mean() > 0.2
     for f in ("t", "u", "v", "shape_id", "prim_id"):
         assert np.array_equal(ho[f].view(np.uint32), ht[f].view(np.uint32)), f
     # bounded segments: any-hit
@@ -96,9 +98,14 @@ def test_bvh_traversal_equals_brute_force(name):
 
 
 def test_unsupported_variants_fail_loudly():
-    """A material alternative the device path does not implement must raise LJ_ERR_UNSUPPORTED, never fall back."""
+    """Anything the device path does not implement must raise LJ_ERR_UNSUPPORTED at upload, never fall back."""
     hs = lj.parse_scene(scene_path("cbox"))
-    hs.desc.materials[0].kind = _abi.LJ_MAT_DISNEYBSDF if hasattr(_abi, "LJ_MAT_DISNEYBSDF") else 8
+    hs.desc.materials[0].kind = 9   # not a Material alternative
     with pytest.raises(RuntimeError) as e:
         Twin(hs)
     assert "not implemented" in str(e.value)
+    hs = lj.parse_scene(scene_path("cbox"))
+    hs.desc.options.integrator = 6  # volpath
+    with pytest.raises(RuntimeError) as e:
+        Twin(hs)
+    assert "integrator" in str(e.value)

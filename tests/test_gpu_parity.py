@@ -6,7 +6,9 @@ Bars:
   * per-sample radiance under identical pcg32 streams: median relative difference < 2e-6, at most 2 % of samples
     diverged by more than 1e-3, crop mean within 2e-4;
   * image: relative L2  ||gpu - oracle|| / ||oracle||  <= 1e-2 at 16 spp (falls as 1/sqrt(spp));
-  * determinism, pool-size independence and rank sharding: bit-exact."""
+  * determinism, pool-size independence and rank sharding: bit-exact;
+  * sponza (tiled image textures amplify the float-vs-double hit point difference, see test_twin_parity.py): wider
+    per-sample bars + a zero-mean test."""
 import numpy as np
 import pytest
 
@@ -22,7 +24,7 @@ def ctx():
     return lj.Context(0)
 
 
-@pytest.fixture(scope="module", params=["cbox", "veach_mi"])
+@pytest.fixture(scope="module", params=["cbox", "veach_mi", "disney_bsdf", "sponza"])
 def scene(request, ctx):
     hs = lj.parse_scene(scene_path(request.param))
     return request.param, hs, lj.Scene(ctx, hs), Oracle(hs)
@@ -33,7 +35,7 @@ def test_intersect_bit_exact(scene):
     rays = random_rays(hs, 1 << 20, 11, o)
     hg = lj.intersect(sc, rays["org"], rays["dir"], 0.0, np.inf)
     ho = o.intersect(rays)
-    assert (ho["shape_id"] >= 0).mean() > 0.3
+    assert (ho["shape_id"] >= 0).mean() > 0.2
     for f in ("t", "u", "v", "shape_id", "prim_id"):
         assert np.array_equal(hg[f].view(np.uint32), ho[f].view(np.uint32)), f
 
@@ -67,7 +69,10 @@ def test_edge_cases_of_the_ray_queries(scene):
     assert hg["shape_id"][0] == -1 and hg["shape_id"][1] == -1 and hg["shape_id"][2] == -1
 
 
-CROPS = {"cbox": [(200, 200, 232, 232), (0, 0, 48, 32)], "veach_mi": [(300, 200, 348, 232), (100, 380, 132, 412)]}
+CROPS = {"cbox": [(200, 200, 232, 232), (0, 0, 48, 32)], "veach_mi": [(300, 200, 348, 232), (100, 380, 132, 412)],
+         "disney_bsdf": [(300, 200, 332, 232), (150, 330, 190, 360)], "sponza": [(300, 300, 332, 332), (420, 100, 452, 132)]}
+BARS = {"sponza": dict(median=1e-4, diverged=0.15, mean=5e-3, l2=3e-2, k=2e-2, img_mean=2e-3)}
+DEFAULT_BARS = dict(median=2e-6, diverged=0.02, mean=2e-4, l2=1e-2, k=5e-3, img_mean=2e-4)
 
 
 def test_per_sample_parity(scene):
@@ -77,24 +82,31 @@ def test_per_sample_parity(scene):
         rc, _, ps, st = o.render(spp=spp, rng_mode=0, crop=crop, per_sample=True)
         assert rc == 0
         pg = lj.render_samples(sc, crop, spp=spp)
-        assert np.isfinite(pg).all() and (pg >= 0).all()
+        bars = BARS.get(name, DEFAULT_BARS)
+        # (negative samples: the reference's bilinear lookup extrapolates for texel coordinates in (-1, 0))
+        assert np.isfinite(pg).all() and ((pg >= 0) | (ps < 0)).all()
         rel = np.abs(pg - ps).max(axis=-1) / np.maximum(np.abs(ps).max(axis=-1), 1e-3)
-        assert np.median(rel) < 2e-6
-        assert (rel > 1e-3).mean() < 0.02
-        assert abs(pg.mean() / ps.mean() - 1) < 2e-4
+        assert np.median(rel) < bars["median"]
+        assert (rel > 1e-3).mean() < bars["diverged"]
+        assert abs(pg.mean() / ps.mean() - 1) < bars["mean"]
+        d = (np.minimum(pg, 4.0) - np.minimum(ps, 4.0)).sum(axis=-1).ravel()
+        assert abs(d.sum()) <= 4.0 * np.sqrt((d * d).sum()) + 1e-6
         k_gpu = sc.stats().bounce_iterations / sc.stats().samples
-        assert abs(k_gpu / (st.bounces / st.samples) - 1) < 5e-3
+        assert abs(k_gpu / (st.bounces / st.samples) - 1) < bars["k"]
 
 
 def test_image_l2_against_oracle(scene):
     name, hs, sc, o = scene
+    bars = BARS.get(name, DEFAULT_BARS)
+    big = hs.desc.n_triangles > 1000
     spp = 16
-    rc, ref, _, _ = o.render(spp=spp, rng_mode=0)
-    img = lj.render(sc, spp=spp)
+    crop = (128, 128, 384, 384) if big else None   # keeps the oracle leg to seconds on the 260 k-triangle scenes
+    rc, ref, _, _ = o.render(spp=spp, rng_mode=0, crop=crop)
+    img = lj.render(sc, spp=spp, crop=crop)
     assert img.shape == (hs.height, hs.width, 3) and np.isfinite(img).all()
     l2 = np.linalg.norm(img - ref) / np.linalg.norm(ref)
-    assert l2 <= 1e-2, l2
-    assert abs(img.mean() / ref.mean() - 1) < 2e-4
+    assert l2 <= bars["l2"], l2
+    assert abs(img.mean() / ref.mean() - 1) < bars["img_mean"]
 
 
 def test_determinism_pool_independence_and_sharding(scene):
@@ -137,9 +149,14 @@ def test_full_size_properties_cbox(ctx):
     assert 2.5 < st.bounce_iterations / st.samples < 3.6
 
 
-def test_unsupported_material_is_refused(ctx):
+def test_unsupported_variants_are_refused(ctx):
     hs = lj.parse_scene(scene_path("cbox"))
-    hs.desc.materials[0].kind = _abi.MATERIAL_KINDS.index("disneyglass")
+    hs.desc.materials[0].kind = 9
+    with pytest.raises(lj.LajollaError) as e:
+        lj.Scene(ctx, hs)
+    assert e.value.code == _abi.LJ_ERR_UNSUPPORTED
+    hs = lj.parse_scene(scene_path("cbox"))
+    hs.desc.options.integrator = 6   # volpath: outside the accelerated path
     with pytest.raises(lj.LajollaError) as e:
         lj.Scene(ctx, hs)
     assert e.value.code == _abi.LJ_ERR_UNSUPPORTED
