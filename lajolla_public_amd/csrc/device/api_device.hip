@@ -13,15 +13,15 @@
 #include <vector>
 
 namespace ljd {
-struct ExtendConfig { int stack; int lds_nodes; int lds_prims; size_t smem; uint32_t refill_min, min_descending; };
+struct ExtendConfig { int stack; int spill_levels; int lds_nodes; int lds_prims; size_t smem; uint32_t refill_min, min_descending; };
 struct ShadeConfig { uint32_t prims_bytes, materials_bytes, lights_bytes, light_cdf_bytes, light_tris_bytes, light_tri_cdf_bytes, stage_prims; size_t smem; };
 ShadeConfig shade_config(size_t n_prims, size_t n_materials, size_t n_lights, size_t n_light_tris, size_t n_light_tri_cdf);
 ExtendConfig extend_config(int n_nodes, int n_prims, int bvh_depth);
 int max_stack_depth();
-void launch_extend(const DScene &sc, const DQueue &q, const DBlockState *blocks, uint32_t n_blocks, uint32_t seg, const ExtendConfig &cfg, hipStream_t s);
+void launch_extend(const DScene &sc, const DQueue &q, const DBlockState *blocks, uint32_t n_blocks, uint32_t seg, const ExtendConfig &cfg, int *spill, hipStream_t s);
 void launch_shade(const DScene &sc, const DPass &pass, const DQueue &q, DBlockState *blocks, uint32_t n_blocks, uint32_t seg, const ShadeConfig &cfg, hipStream_t s);
 void launch_resolve(const DPass &pass, uint32_t n_pixels, float *rgb, hipStream_t s);
-void launch_trace_rays(const DScene &sc, const void *rays, long long n, void *hits, unsigned char *occ, const ExtendConfig &cfg, int grid, hipStream_t s);
+void launch_trace_rays(const DScene &sc, const void *rays, long long n, void *hits, unsigned char *occ, const ExtendConfig &cfg, int *spill, int grid, hipStream_t s);
 }
 
 namespace {
@@ -55,6 +55,7 @@ struct lj_context {
     int n_cus = 256;
     // workspace, grown on demand and reused across renders
     DevBuf queue_mem; uint32_t queue_capacity = 0;
+    DevBuf spill;  // overflow levels of the traversal stacks: spill_levels x (grid * 256) ints
     DevBuf blocks, sample_rgb, pixel_list, frame;
     ljd::DBlockState *blocks_host = nullptr;  // pinned, kMaxBlocks entries
     hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_k0 = nullptr, ev_k1 = nullptr;
@@ -90,6 +91,14 @@ void ensure_queues(lj_context *ctx, uint32_t cap) {
     cap = (cap + 63u) & ~63u;
     ctx->queue_mem.alloc(queue_bytes(cap));
     ctx->queue_capacity = cap;
+}
+
+// overflow stack storage for a launch of `grid` workgroups over a scene whose BVH needs `levels` levels beyond LDS
+int *ensure_spill(lj_context *ctx, int levels, uint32_t grid) {
+    if (levels <= 0) return nullptr;
+    const size_t need = (size_t)levels * grid * 256 * sizeof(int);
+    if (ctx->spill.bytes < need) ctx->spill.alloc(need);
+    return (int *)ctx->spill.p;
 }
 
 struct RenderPlan {
@@ -151,6 +160,7 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
     uint32_t seg = ((pool + n_blocks - 1) / n_blocks + 255u) & ~255u;
     const uint32_t n_slots = n_blocks * seg;
     ensure_queues(ctx, n_slots);
+    int *spill = ensure_spill(ctx, sc->ecfg.spill_levels, n_blocks);
     ljd::DQueue q = carve_queue(ctx->queue_mem.p, ctx->queue_capacity);
     if (ctx->sample_rgb.bytes < pass_samples_max * 12) ctx->sample_rgb.alloc(pass_samples_max * 12);
     if (ctx->pixel_list.bytes < n_pix * 4) ctx->pixel_list.alloc(n_pix * 4);
@@ -182,7 +192,7 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
             const int batch = 8;  // steps per host round trip; all per-step state lives on the device
             for (int b = 0; b < batch; b++) {
                 if (timing) HIP_CHECK(hipEventRecord(ctx->ev_k0, stream));
-                ljd::launch_extend(ds, q, dblocks, n_blocks, seg, sc->ecfg, stream);
+                ljd::launch_extend(ds, q, dblocks, n_blocks, seg, sc->ecfg, spill, stream);
                 if (timing) HIP_CHECK(hipEventRecord(ctx->ev_k1, stream));
                 ljd::launch_shade(ds, pass, q, dblocks, n_blocks, seg, sc->scfg, stream);
                 if (timing) {
@@ -280,7 +290,7 @@ int lj_scene_upload(lj_context *ctx, const LjSceneDesc *desc, lj_scene **out) {
         upload(sc->images3, F.images3, s); upload(sc->images1, F.images1, s); upload(sc->texels, F.texels, s); upload(sc->env_tables, F.env_tables, s);
         HIP_CHECK(hipStreamSynchronize(s));
         ljd::DScene d = F.host_view();
-        d.nodes = (const ljd::DNode *)sc->nodes.p; d.leaf_prims = (const ljd::DPrim *)sc->leaf_prims.p; d.prims = (const ljd::DPrimShade *)sc->prims.p;
+        d.nodes = (const ljd::DNode4 *)sc->nodes.p; d.leaf_prims = (const ljd::DPrim *)sc->leaf_prims.p; d.prims = (const ljd::DPrimShade *)sc->prims.p;
         d.spheres = (const ljd::DSphere *)sc->spheres.p; d.materials = (const ljd::DMaterial *)sc->materials.p; d.lights = (const ljd::DLight *)sc->lights.p;
         d.light_cdf = (const float *)sc->light_cdf.p; d.light_tris = (const ljd::DLightTri *)sc->light_tris.p; d.light_tri_cdf = (const float *)sc->light_tri_cdf.p;
         d.images3 = (const ljd::DImage *)sc->images3.p; d.images1 = (const ljd::DImage *)sc->images1.p; d.texels = (const float *)sc->texels.p; d.env_tables = (const float *)sc->env_tables.p;
@@ -351,7 +361,7 @@ static int trace_batch(lj_scene *scene, int64_t n, const LjRay *rays_host, LjHit
         out.alloc((size_t)n * (hits_host ? sizeof(LjHit) : 1));
         HIP_CHECK(hipMemcpyAsync(rays.p, rays_host, (size_t)n * sizeof(LjRay), hipMemcpyHostToDevice, ctx->stream));
         int grid = (int)std::min<int64_t>((n + 255) / 256, ctx->n_cus * 4);
-        ljd::launch_trace_rays(scene->dscene, rays.p, n, hits_host ? out.p : nullptr, hits_host ? nullptr : (unsigned char *)out.p, scene->ecfg, grid, ctx->stream);
+        ljd::launch_trace_rays(scene->dscene, rays.p, n, hits_host ? out.p : nullptr, hits_host ? nullptr : (unsigned char *)out.p, scene->ecfg, ensure_spill(ctx, scene->ecfg.spill_levels, (uint32_t)grid), grid, ctx->stream);
         HIP_CHECK(hipGetLastError());
         if (hits_host) HIP_CHECK(hipMemcpyAsync(hits_host, out.p, (size_t)n * sizeof(LjHit), hipMemcpyDeviceToHost, ctx->stream));
         else HIP_CHECK(hipMemcpyAsync(occ_host, out.p, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));

@@ -70,20 +70,41 @@ LJ_HD bool sphere_test(const RayF &r, const DSphere &s, double &t_out) {
     return false;
 }
 
-LJ_HD bool box_test(const float *lo, const float *hi, const RayF &r, float ix, float iy, float iz, float tfar, float &tentry) {
-    float ax = (lo[0] - r.ox) * ix, bx = (hi[0] - r.ox) * ix;
-    float ay = (lo[1] - r.oy) * iy, by = (hi[1] - r.oy) * iy;
-    float az = (lo[2] - r.oz) * iz, bz = (hi[2] - r.oz) * iz;
-    float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), r.tnear));
-    float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tfar));
+// Slab test of child `k` of a BVH4 node.  The ray's direction signs pick the near and the far plane of every axis, so
+// an empty slot (lo = +inf, hi = -inf) can never be entered.  The factor widens the exit distance by 4 ulp: the test
+// may accept a box the exact ray misses, never the reverse (boxes are padded by the builder on top of that).
+LJ_HD bool box_test4(const DNode4 &nd, int k, const RayF &r, float ix, float iy, float iz, float tfar, float &tentry) {
+    const float nx = ix < 0.0f ? nd.hix[k] : nd.lox[k], fx = ix < 0.0f ? nd.lox[k] : nd.hix[k];
+    const float ny = iy < 0.0f ? nd.hiy[k] : nd.loy[k], fy = iy < 0.0f ? nd.loy[k] : nd.hiy[k];
+    const float nz = iz < 0.0f ? nd.hiz[k] : nd.loz[k], fz = iz < 0.0f ? nd.loz[k] : nd.hiz[k];
+    const float t0 = fmaxf(fmaxf((nx - r.ox) * ix, (ny - r.oy) * iy), fmaxf((nz - r.oz) * iz, r.tnear));
+    const float t1 = fminf(fminf((fx - r.ox) * ix, (fy - r.oy) * iy), fminf((fz - r.oz) * iz, tfar));
     tentry = t0;
     return t0 <= t1 * 1.0000005f;
 }
 
 struct HitRec { float t, u, v; int32_t gprim; };
 
-// Mem provides: DNode node(int i); DPrim prim(int i); const DSphere& sphere(int slot);
-//               void push(int sp, int v); int pop(int sp);   (per-lane stack storage), int max_stack()
+// Closest-hit / any-hit update for one primitive of a leaf; returns true when an any-hit query is finished.
+template <bool ANY_HIT, class Mem>
+LJ_HD bool leaf_prim_test(Mem &mem, const RayF &ray, const DPrim &p, HitRec &best) {
+    float t, u = 0.0f, v = 0.0f;
+    if (p.kind == 0) {
+        if (!tri_test(ray, best.t, p.v0, p.v1, p.v2, t, u, v)) return false;
+    } else {
+        double td;
+        if (!sphere_test(ray, mem.sphere(p.sphere_slot), td)) return false;
+        t = (float)td;
+    }
+    if (ANY_HIT) { best.t = t; best.gprim = p.gprim; return true; }
+    if (t < best.t || (t == best.t && (best.gprim < 0 || p.gprim < best.gprim))) { best.t = t; best.u = u; best.v = v; best.gprim = p.gprim; }
+    return false;
+}
+
+// Reference form of the traversal the extend kernel performs (kernels.hip keeps a wave-synchronous version of the same
+// steps): hit children are visited nearest first, the others wait on the stack.
+// Mem provides: DNode4 node(int i); DPrim prim(int i); const DSphere& sphere(int slot);
+//               void push(int sp, int v); int pop(int sp);   (per-lane stack storage, 3 * bvh depth entries)
 template <bool ANY_HIT, class Mem>
 LJ_HD bool traverse(Mem &mem, const RayF &ray, HitRec &best) {
     best.t = ray.tfar; best.u = 0.0f; best.v = 0.0f; best.gprim = -1;
@@ -91,43 +112,27 @@ LJ_HD bool traverse(Mem &mem, const RayF &ray, HitRec &best) {
     int sp = 0;
     int cur = 0;
     for (;;) {
-        const DNode nd = mem.node(cur);
-        float te0, te1;
-        bool h0 = box_test(nd.lo0, nd.hi0, ray, ix, iy, iz, best.t, te0);
-        bool h1 = box_test(nd.lo1, nd.hi1, ray, ix, iy, iz, best.t, te1);
-#pragma unroll 1
-        for (int side = 0; side < 2; side++) {
-            const int c = side ? nd.c1 : nd.c0;
-            const bool h = side ? h1 : h0;
-            if (!h || c >= 0) continue;
-            const int first = (~c) >> 3, count = ((~c) & 7) + 1;
-            for (int k = 0; k < count; k++) {
-                const DPrim p = mem.prim(first + k);
-                if (p.kind == 0) {
-                    float t, u, v;
-                    if (tri_test(ray, best.t, p.v0, p.v1, p.v2, t, u, v)) {
-                        if (ANY_HIT) { best.t = t; best.gprim = p.gprim; return true; }
-                        if (t < best.t || (t == best.t && (best.gprim < 0 || p.gprim < best.gprim))) { best.t = t; best.u = u; best.v = v; best.gprim = p.gprim; }
-                    }
-                } else {
-                    double td;
-                    if (sphere_test(ray, mem.sphere(p.sphere_slot), td)) {
-                        const float tf = (float)td;
-                        if (ANY_HIT) { best.t = tf; best.gprim = p.gprim; return true; }
-                        if (tf < best.t || (tf == best.t && (best.gprim < 0 || p.gprim < best.gprim))) { best.t = tf; best.u = 0.0f; best.v = 0.0f; best.gprim = p.gprim; }
-                    }
-                }
+        if (cur >= 0) {
+            const DNode4 nd = mem.node(cur);
+            float td[4]; int cd[4]; int nh = 0;
+            for (int k = 0; k < 4; k++) {
+                float te;
+                if (!box_test4(nd, k, ray, ix, iy, iz, best.t, te)) continue;
+                int pos = nh++;
+                while (pos > 0 && td[pos - 1] > te) { td[pos] = td[pos - 1]; cd[pos] = cd[pos - 1]; pos--; }
+                td[pos] = te; cd[pos] = nd.child[k];
             }
-        }
-        const bool g0 = h0 && nd.c0 >= 0, g1 = h1 && nd.c1 >= 0;
-        if (g0 && g1) {
-            const bool near0 = te0 <= te1;
-            const int nearc = near0 ? nd.c0 : nd.c1, farc = near0 ? nd.c1 : nd.c0;
-            if (sp < mem.max_stack()) { mem.push(sp, farc); sp++; }
-            cur = nearc;
-        } else if (g0) cur = nd.c0;
-        else if (g1) cur = nd.c1;
-        else {
+            if (nh == 0) {
+                if (sp == 0) break;
+                sp--; cur = mem.pop(sp);
+            } else {
+                for (int k = nh - 1; k >= 1; k--) { mem.push(sp, cd[k]); sp++; }
+                cur = cd[0];
+            }
+        } else {
+            const int first = (~cur) >> 3, count = ((~cur) & 7) + 1;
+            for (int k = 0; k < count; k++)
+                if (leaf_prim_test<ANY_HIT>(mem, ray, mem.prim(first + k), best)) return true;
             if (sp == 0) break;
             sp--; cur = mem.pop(sp);
         }

@@ -11,17 +11,18 @@
 
 namespace ljd {
 
-// ---- BVH2, both child boxes stored in the parent (one 64-byte record per traversal step).
+// ---- BVH4: the boxes of all four children live in the parent, structure-of-arrays by axis, so one traversal step is
+// one 128-byte line and the ray's direction signs pick the "near" and "far" quarter of every axis by address alone.
 // child >= 0: inner node index.  child < 0: leaf; ~child = first * 8 + (count - 1) addresses prims
-// [first, first + count) of the leaf-ordered prim array (count <= 8).  n0 / n1 repeat the counts.
-// An empty child has lo = +inf, hi = -inf.
-struct DNode {
-    float lo0[3]; int32_t c0;
-    float hi0[3]; int32_t c1;
-    float lo1[3]; int32_t n0;
-    float hi1[3]; int32_t n1;
+// [first, first + count) of the leaf-ordered prim array (count <= 8).
+// An empty slot has lo = +inf, hi = -inf: with sign-selected slabs its entry distance is +inf and its exit -inf.
+struct DNode4 {
+    float lox[4], loy[4], loz[4];   // quarters 0-2: lower corners of the four children, one axis per 16-byte quarter
+    float hix[4], hiy[4], hiz[4];   // quarters 3-5: upper corners
+    int32_t child[4];               // quarter 6: >= 0 inner node index, < 0 leaf code ~(first * 8 + count - 1)
+    int32_t pad[4];                 // quarter 7: keeps a node on exactly one 128-byte line
 };
-static_assert(sizeof(DNode) == 64, "DNode must be 64 bytes");
+static_assert(sizeof(DNode4) == 128, "DNode4 must be 128 bytes");
 
 // Leaf-ordered primitive for the intersection tests (48 bytes = three float4).
 // kind 0: triangle, float vertices exactly as the reference hands them to Embree (triangle_mesh.inl:11-14).
@@ -93,7 +94,7 @@ struct DCamera {
 
 struct DScene {
     DCamera cam;
-    const DNode *nodes; int32_t n_nodes;
+    const DNode4 *nodes; int32_t n_nodes;
     const DPrim *leaf_prims; int32_t n_prims;
     const DPrimShade *prims;
     const DSphere *spheres;          // indexed by sphere_slot

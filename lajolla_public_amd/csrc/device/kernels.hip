@@ -47,36 +47,40 @@ __device__ __forceinline__ void q_store(const DQueue &q, uint32_t i, const PathS
 }
 
 // ---------------------------------------------------------------- extend
-// LDS image (dynamic): [ per-lane stacks: STACK x 256 ints ][ first n_lnodes BVH nodes ][ first n_lprims leaf prims ]
+// LDS image (dynamic): [ per-lane stacks: cap x 256 ints ][ first n_lnodes BVH4 nodes ][ first n_lprims leaf prims ]
 // Nodes are stored breadth-first, so a prefix of the node array is the top of the tree.
 struct TreeView {
-    const v4f *gnodes; const v4f *gprims; const DSphere *spheres;
-    const LJ_LDS v4f *lnodes; const LJ_LDS v4f *lprims;
-    LJ_LDS int *stack;  // this lane's column; level l lives at stack[l * kBlock]
-    int n_lnodes, n_lprims, node_stride, prim_stride;
+    const char *gnodes; const v4f *gprims; const DSphere *spheres;
+    const LJ_LDS char *lnodes; const LJ_LDS v4f *lprims;
+    LJ_LDS int *stack;   // this lane's column; level l lives at stack[l * kBlock]
+    int *spill;          // this lane's column of the overflow stack in global memory (levels >= cap), stride spill_stride
+    uint32_t spill_stride;
+    int n_lnodes, n_lprims, prim_stride, cap;
+    uint32_t qstride;    // bytes between two quarters of one node in the LDS image (= staged nodes * 16)
 };
 
 extern __shared__ __attribute__((aligned(16))) v4f lj_smem[];
 
-template <int STACK>
-__device__ __forceinline__ TreeView stage_tree(const DScene &sc, int lds_nodes, int lds_prims) {
+__device__ __forceinline__ TreeView stage_tree(const DScene &sc, int stack, int lds_nodes, int lds_prims, int *spill, uint32_t spill_stride, uint32_t lane_global) {
     TreeView tv;
     LJ_LDS v4f *base = (LJ_LDS v4f *)lj_smem;
     tv.stack = (LJ_LDS int *)base + threadIdx.x;
-    LJ_LDS v4f *ln = base + (STACK * kBlock) / 4;
-    LJ_LDS v4f *lp = ln + lds_nodes * 4;
+    tv.cap = stack;
+    tv.spill = spill + lane_global; tv.spill_stride = spill_stride;
+    LJ_LDS v4f *ln = base + (stack * kBlock) / 4;
+    LJ_LDS v4f *lp = ln + lds_nodes * 7;
     tv.n_lnodes = sc.n_nodes < lds_nodes ? sc.n_nodes : lds_nodes;
     tv.n_lprims = sc.n_prims < lds_prims ? sc.n_prims : lds_prims;
-    tv.node_stride = lds_nodes; tv.prim_stride = lds_prims;
+    tv.qstride = (uint32_t)lds_nodes * 16u; tv.prim_stride = lds_prims;
     // The LDS image is transposed: quarter k of node i sits at ln[k * lds_nodes + i].  Lanes that fetch different
-    // nodes then hit different 16-byte bank slots (a 64-byte stride would put every node on the same four).
+    // nodes then hit different 16-byte bank slots (a 128-byte stride would put every node on the same four).
     const v4f *src = reinterpret_cast<const v4f *>(sc.nodes);
-    for (int i = threadIdx.x; i < tv.n_lnodes * 4; i += kBlock) ln[(i & 3) * lds_nodes + (i >> 2)] = src[i];
+    for (int i = threadIdx.x; i < tv.n_lnodes * 7; i += kBlock) { const int node = i / 7, k = i - node * 7; ln[k * lds_nodes + node] = src[node * 8 + k]; }
     src = reinterpret_cast<const v4f *>(sc.leaf_prims);
     for (int i = threadIdx.x; i < tv.n_lprims * 3; i += kBlock) lp[(i % 3) * lds_prims + (i / 3)] = src[i];
     __syncthreads();
-    tv.gnodes = reinterpret_cast<const v4f *>(sc.nodes); tv.gprims = reinterpret_cast<const v4f *>(sc.leaf_prims);
-    tv.spheres = sc.spheres; tv.lnodes = ln; tv.lprims = lp;
+    tv.gnodes = reinterpret_cast<const char *>(sc.nodes); tv.gprims = reinterpret_cast<const v4f *>(sc.leaf_prims);
+    tv.spheres = sc.spheres; tv.lnodes = (const LJ_LDS char *)ln; tv.lprims = lp;
     return tv;
 }
 
@@ -86,40 +90,73 @@ struct LaneTrav {
     RayF ray; float ix, iy, iz;
     HitRec best;
     int cur, sp;
+    uint32_t nqx, nqy, nqz;  // quarter index (0..5) holding the NEAR plane of each axis for this ray's direction signs
 };
 
 __device__ __forceinline__ void trav_begin(LaneTrav &L, float tnear, float tfar) {
     L.ray.tnear = tnear; L.ray.tfar = tfar;
     L.ix = 1.0f / L.ray.dx; L.iy = 1.0f / L.ray.dy; L.iz = 1.0f / L.ray.dz;
+    L.nqx = L.ix < 0.0f ? 3u : 0u; L.nqy = L.iy < 0.0f ? 4u : 1u; L.nqz = L.iz < 0.0f ? 5u : 2u;
     L.best.t = tfar; L.best.u = 0.0f; L.best.v = 0.0f; L.best.gprim = -1;
     L.cur = 0; L.sp = 0;
+}
+__device__ __forceinline__ void trav_push(const TreeView &tv, LaneTrav &L, int v) {
+    if (L.sp < tv.cap) tv.stack[L.sp * kBlock] = v;
+    else tv.spill[(uint32_t)(L.sp - tv.cap) * tv.spill_stride] = v;
+    L.sp++;
 }
 __device__ __forceinline__ int trav_pop(const TreeView &tv, LaneTrav &L) {
     if (L.sp == 0) return kDone;
     L.sp--;
-    return tv.stack[L.sp * kBlock];
+    if (L.sp < tv.cap) return tv.stack[L.sp * kBlock];
+    return tv.spill[(uint32_t)(L.sp - tv.cap) * tv.spill_stride];
 }
 
-// one inner-node step: test both child boxes, continue with the nearer hit child, push the other
-template <int STACK>
+__device__ __forceinline__ void csw(float &ta, int &ca, float &tb, int &cb) {  // compare-exchange: nearer entry first
+    const bool sw = tb < ta;
+    const float t0 = sw ? tb : ta, t1 = sw ? ta : tb; const int c0 = sw ? cb : ca, c1 = sw ? ca : cb;
+    ta = t0; tb = t1; ca = c0; cb = c1;
+}
+
+// one inner-node step: slab-test the four children, continue with the nearest one that is hit, push the others far-first
 __device__ __forceinline__ void trav_node_step(const TreeView &tv, LaneTrav &L) {
-    v4f a, b, c, d;
+    v4f nx, ny, nz, fx, fy, fz, ch;
     const int i = L.cur;
-    if (i < tv.n_lnodes) { const int S = tv.node_stride; a = tv.lnodes[i]; b = tv.lnodes[S + i]; c = tv.lnodes[2 * S + i]; d = tv.lnodes[3 * S + i]; }
-    else { a = tv.gnodes[4 * i]; b = tv.gnodes[4 * i + 1]; c = tv.gnodes[4 * i + 2]; d = tv.gnodes[4 * i + 3]; }
-    const float lo0[3] = {a.x, a.y, a.z}, hi0[3] = {b.x, b.y, b.z}, lo1[3] = {c.x, c.y, c.z}, hi1[3] = {d.x, d.y, d.z};
-    const int c0 = __float_as_int(a.w), c1 = __float_as_int(b.w);
-    float te0, te1;
-    const bool h0 = box_test(lo0, hi0, L.ray, L.ix, L.iy, L.iz, L.best.t, te0);
-    const bool h1 = box_test(lo1, hi1, L.ray, L.ix, L.iy, L.iz, L.best.t, te1);
-    if (h0 && h1) {
-        const bool near0 = te0 <= te1;
-        const int nearc = near0 ? c0 : c1, farc = near0 ? c1 : c0;
-        if (L.sp < STACK) { tv.stack[L.sp * kBlock] = farc; L.sp++; }
-        L.cur = nearc;
-    } else if (h0) L.cur = c0;
-    else if (h1) L.cur = c1;
-    else L.cur = trav_pop(tv, L);
+    if (i < tv.n_lnodes) {
+        const LJ_LDS char *b = tv.lnodes + (uint32_t)i * 16u;
+        const uint32_t S = tv.qstride;
+        nx = *(const LJ_LDS v4f *)(b + L.nqx * S); fx = *(const LJ_LDS v4f *)(b + (3u - L.nqx) * S);
+        ny = *(const LJ_LDS v4f *)(b + L.nqy * S); fy = *(const LJ_LDS v4f *)(b + (5u - L.nqy) * S);
+        nz = *(const LJ_LDS v4f *)(b + L.nqz * S); fz = *(const LJ_LDS v4f *)(b + (7u - L.nqz) * S);
+        ch = *(const LJ_LDS v4f *)(b + 6u * S);
+    } else {
+        const char *g = tv.gnodes;
+        const uint32_t o = (uint32_t)i * 128u;
+        nx = *(const v4f *)(g + (o + L.nqx * 16u)); fx = *(const v4f *)(g + (o + (3u - L.nqx) * 16u));
+        ny = *(const v4f *)(g + (o + L.nqy * 16u)); fy = *(const v4f *)(g + (o + (5u - L.nqy) * 16u));
+        nz = *(const v4f *)(g + (o + L.nqz * 16u)); fz = *(const v4f *)(g + (o + (7u - L.nqz) * 16u));
+        ch = *(const v4f *)(g + (o + 96u));
+    }
+    const v4f tnx = (nx - L.ray.ox) * L.ix, tfx = (fx - L.ray.ox) * L.ix;
+    const v4f tny = (ny - L.ray.oy) * L.iy, tfy = (fy - L.ray.oy) * L.iy;
+    const v4f tnz = (nz - L.ray.oz) * L.iz, tfz = (fz - L.ray.oz) * L.iz;
+    const float inf = __builtin_inff();
+    float t0[4]; int c[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float te = fmaxf(fmaxf(tnx[k], tny[k]), fmaxf(tnz[k], L.ray.tnear));
+        const float tx = fminf(fminf(tfx[k], tfy[k]), fminf(tfz[k], L.best.t));
+        t0[k] = (te <= tx * 1.0000005f) ? te : inf;
+        c[k] = __float_as_int(ch[k]);
+    }
+    // (an entry distance is finite for a hit: it is bounded by best.t or by the finite far planes)
+    csw(t0[0], c[0], t0[1], c[1]); csw(t0[2], c[2], t0[3], c[3]);
+    csw(t0[0], c[0], t0[2], c[2]); csw(t0[1], c[1], t0[3], c[3]);
+    csw(t0[1], c[1], t0[2], c[2]);
+    if (t0[3] < inf) trav_push(tv, L, c[3]);
+    if (t0[2] < inf) trav_push(tv, L, c[2]);
+    if (t0[1] < inf) trav_push(tv, L, c[1]);
+    L.cur = (t0[0] < inf) ? c[0] : trav_pop(tv, L);
 }
 
 // one leaf: up to 8 primitives
@@ -152,9 +189,8 @@ __device__ __forceinline__ void trav_leaf_step(const TreeView &tv, LaneTrav &L, 
     L.cur = stop ? kDone : trav_pop(tv, L);
 }
 
-template <int STACK>
-__global__ void __launch_bounds__(kBlock, 4) k_extend(DScene sc, DQueue q, const DBlockState *blocks, uint32_t seg, int lds_nodes, int lds_prims, uint32_t refill_min, uint32_t min_descending) {
-    const TreeView tv = stage_tree<STACK>(sc, lds_nodes, lds_prims);
+__global__ void __launch_bounds__(kBlock, 4) k_extend(DScene sc, DQueue q, const DBlockState *blocks, uint32_t seg, int stack, int lds_nodes, int lds_prims, int *spill, uint32_t refill_min, uint32_t min_descending) {
+    const TreeView tv = stage_tree(sc, stack, lds_nodes, lds_prims, spill, gridDim.x * kBlock, blockIdx.x * kBlock + threadIdx.x);
     // workgroup b traces segment b; its four waves split the live front of the segment into contiguous slices
     const uint32_t count = blocks[blockIdx.x].count, seg_base = blockIdx.x * seg;
     uint32_t slice = ((count + (kBlock / 64) - 1) / (kBlock / 64) + 63u) & ~63u;
@@ -201,7 +237,7 @@ __global__ void __launch_bounds__(kBlock, 4) k_extend(DScene sc, DQueue q, const
             if (dm == 0ull) break;
             // only hand over to the leaf phase if some lane actually has a leaf to test (otherwise no progress is made)
             if ((uint32_t)__popcll(dm) < min_descending && __ballot(busy && L.cur < 0) != 0ull) break;
-            if (descending) trav_node_step<STACK>(tv, L);
+            if (descending) trav_node_step(tv, L);
         }
         // ... then all of them test their leaf together
         if (busy && L.cur < 0) trav_leaf_step(tv, L, phase == 0);
@@ -324,16 +360,15 @@ __global__ void __launch_bounds__(kBlock) k_resolve(DPass pass, uint32_t n_pixel
 struct RayIO { float org[3]; float tnear; float dir[3]; float tfar; };
 struct HitIO { float t, u, v; int32_t shape_id, prim_id; };
 
-template <int STACK>
-__global__ void __launch_bounds__(kBlock) k_trace_rays(DScene sc, const RayIO *rays, long long n, HitIO *hits, unsigned char *occ, int lds_nodes, int lds_prims) {
-    const TreeView tv = stage_tree<STACK>(sc, lds_nodes, lds_prims);
+__global__ void __launch_bounds__(kBlock) k_trace_rays(DScene sc, const RayIO *rays, long long n, HitIO *hits, unsigned char *occ, int stack, int lds_nodes, int lds_prims, int *spill) {
+    const TreeView tv = stage_tree(sc, stack, lds_nodes, lds_prims, spill, gridDim.x * kBlock, blockIdx.x * kBlock + threadIdx.x);
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
         LaneTrav L;
         L.ray.ox = rays[i].org[0]; L.ray.oy = rays[i].org[1]; L.ray.oz = rays[i].org[2];
         L.ray.dx = rays[i].dir[0]; L.ray.dy = rays[i].dir[1]; L.ray.dz = rays[i].dir[2];
         trav_begin(L, rays[i].tnear, rays[i].tfar);
         while (L.cur != kDone) {
-            while (L.cur >= 0 && L.cur != kDone) trav_node_step<STACK>(tv, L);
+            while (L.cur >= 0 && L.cur != kDone) trav_node_step(tv, L);
             if (L.cur < 0) trav_leaf_step(tv, L, occ != nullptr);
         }
         if (occ) occ[i] = L.best.gprim >= 0 ? 1 : 0;
@@ -349,26 +384,28 @@ __global__ void __launch_bounds__(kBlock) k_trace_rays(DScene sc, const RayIO *r
 }
 
 // ---------------------------------------------------------------- launchers (called from api_device.hip)
-// Two stack depths are compiled: 16 levels cover every small scene, 40 the deepest BVH the builder may emit.
-// LDS per 256-thread workgroup = STACK * 1 KiB + staged nodes * 64 B + staged prims * 48 B.
-struct ExtendConfig { int stack; int lds_nodes; int lds_prims; size_t smem; uint32_t refill_min, min_descending; };
+// A traversal of a BVH4 with `depth` inner levels holds at most 3 * depth entries.  The first `stack` levels of every
+// lane's stack live in LDS (1 KiB per level and workgroup); deeper levels — rare — go to a global overflow buffer.
+// LDS per 256-thread workgroup = stack * 1 KiB + staged nodes * 112 B + staged prims * 48 B; four workgroups share a
+// CU's 160 KiB, so the budget per workgroup is 40 KiB.
+struct ExtendConfig { int stack; int spill_levels; int lds_nodes; int lds_prims; size_t smem; uint32_t refill_min, min_descending; };
 
 ExtendConfig extend_config(int n_nodes, int n_prims, int bvh_depth) {
     ExtendConfig c;
-    if (bvh_depth <= 16) {
-        c.stack = 16;
-        c.lds_nodes = n_nodes < 256 ? n_nodes : 256;       // <= 16 KiB of nodes
-        c.lds_prims = n_prims <= 256 ? n_prims : 0;        // primitives only when the whole scene fits (<= 12 KiB)
-    } else {
-        c.stack = 40;
-        c.lds_nodes = n_nodes < 256 ? n_nodes : 256;
-        c.lds_prims = 0;
-    }
-    c.smem = (size_t)c.stack * kBlock * 4 + (size_t)c.lds_nodes * 64 + (size_t)c.lds_prims * 48;
+    const int need = 3 * (bvh_depth < 1 ? 1 : bvh_depth);
+    c.stack = need < 16 ? need : 16;
+    c.spill_levels = need - c.stack;
+    const int budget = 40 * 1024 - 256 - c.stack * kBlock * 4;
+    const int small = n_prims <= 256;                                     // primitives only when the whole scene fits (<= 12 KiB)
+    c.lds_prims = small ? n_prims : 0;
+    int max_nodes = (budget - c.lds_prims * 48) / 112;
+    if (max_nodes < 0) max_nodes = 0;
+    c.lds_nodes = n_nodes < max_nodes ? n_nodes : max_nodes;
+    c.smem = (size_t)c.stack * kBlock * 4 + (size_t)c.lds_nodes * 112 + (size_t)c.lds_prims * 48;
     c.refill_min = 8; c.min_descending = 1;  // tuned on cbox / MI355X (tools/tune.sh)
     return c;
 }
-int max_stack_depth() { return 40; }
+int max_stack_depth() { return 40; }  // inner levels; the builder's own cap is 38
 
 // LDS staging plan of the shade kernel; sizes are rounded up to 16 bytes (the device buffers are padded accordingly).
 struct ShadeConfig { uint32_t prims_bytes, materials_bytes, lights_bytes, light_cdf_bytes, light_tris_bytes, light_tri_cdf_bytes, stage_prims; size_t smem; };
@@ -388,9 +425,8 @@ ShadeConfig shade_config(size_t n_prims, size_t n_materials, size_t n_lights, si
     return c;
 }
 
-void launch_extend(const DScene &sc, const DQueue &q, const DBlockState *blocks, uint32_t n_blocks, uint32_t seg, const ExtendConfig &cfg, hipStream_t s) {
-    if (cfg.stack == 16) hipLaunchKernelGGL((k_extend<16>), dim3(n_blocks), dim3(kBlock), cfg.smem, s, sc, q, blocks, seg, cfg.lds_nodes, cfg.lds_prims, cfg.refill_min, cfg.min_descending);
-    else hipLaunchKernelGGL((k_extend<40>), dim3(n_blocks), dim3(kBlock), cfg.smem, s, sc, q, blocks, seg, cfg.lds_nodes, cfg.lds_prims, cfg.refill_min, cfg.min_descending);
+void launch_extend(const DScene &sc, const DQueue &q, const DBlockState *blocks, uint32_t n_blocks, uint32_t seg, const ExtendConfig &cfg, int *spill, hipStream_t s) {
+    hipLaunchKernelGGL(k_extend, dim3(n_blocks), dim3(kBlock), cfg.smem, s, sc, q, blocks, seg, cfg.stack, cfg.lds_nodes, cfg.lds_prims, spill, cfg.refill_min, cfg.min_descending);
 }
 void launch_shade(const DScene &sc, const DPass &pass, const DQueue &q, DBlockState *blocks, uint32_t n_blocks, uint32_t seg, const ShadeConfig &cfg, hipStream_t s) {
     ShadeStage st;
@@ -403,9 +439,8 @@ void launch_resolve(const DPass &pass, uint32_t n_pixels, float *rgb, hipStream_
     const uint32_t grid = (n_pixels + waves_per_block - 1) / waves_per_block;
     if (grid) hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(kBlock), 0, s, pass, n_pixels, rgb);
 }
-void launch_trace_rays(const DScene &sc, const void *rays, long long n, void *hits, unsigned char *occ, const ExtendConfig &cfg, int grid, hipStream_t s) {
-    if (cfg.stack == 16) hipLaunchKernelGGL((k_trace_rays<16>), dim3(grid), dim3(kBlock), cfg.smem, s, sc, (const RayIO *)rays, n, (HitIO *)hits, occ, cfg.lds_nodes, cfg.lds_prims);
-    else hipLaunchKernelGGL((k_trace_rays<40>), dim3(grid), dim3(kBlock), cfg.smem, s, sc, (const RayIO *)rays, n, (HitIO *)hits, occ, cfg.lds_nodes, cfg.lds_prims);
+void launch_trace_rays(const DScene &sc, const void *rays, long long n, void *hits, unsigned char *occ, const ExtendConfig &cfg, int *spill, int grid, hipStream_t s) {
+    hipLaunchKernelGGL(k_trace_rays, dim3(grid), dim3(kBlock), cfg.smem, s, sc, (const RayIO *)rays, n, (HitIO *)hits, occ, cfg.stack, cfg.lds_nodes, cfg.lds_prims, spill);
 }
 
 } // namespace ljd

@@ -1,6 +1,7 @@
 // Host BVH builder: replaces Embree's rtcCommitScene (scene.cpp:20-27, build quality HIGH) with a binned-SAH
-// BVH2 whose nodes are emitted breadth-first — a prefix of the node array is the top of the tree, which is what the
-// extend kernel stages into LDS.  Each node record carries both children's boxes (one 64-byte fetch per step).
+// binary tree collapsed into a BVH4 (largest-area child opened first) whose nodes are emitted breadth-first — a
+// prefix of the node array is the top of the tree, which is what the extend kernel stages into LDS.  Each node record
+// carries the boxes of its four children (one 128-byte fetch per step).
 #include "flatten.h"
 #include <algorithm>
 #include <cmath>
@@ -101,52 +102,66 @@ struct Builder {
 } // namespace
 
 void build_bvh(const std::vector<BuildPrim> &prims, int max_leaf, int max_depth,
-               std::vector<ljd::DNode> &nodes, std::vector<int> &leaf_order, int &depth_out) {
+               std::vector<ljd::DNode4> &nodes, std::vector<int> &leaf_order, int &depth_out) {
     nodes.clear(); leaf_order.clear(); depth_out = 0;
     const int n = (int)prims.size();
-    auto empty_child = [](float *lo, float *hi) { for (int k = 0; k < 3; k++) { lo[k] = std::numeric_limits<float>::infinity(); hi[k] = -std::numeric_limits<float>::infinity(); } };
-    if (n == 0) {
-        ljd::DNode nd{}; empty_child(nd.lo0, nd.hi0); empty_child(nd.lo1, nd.hi1); nd.c0 = nd.c1 = -1; nd.n0 = nd.n1 = 0;
-        nodes.push_back(nd);
-        return;
-    }
+    const float inf = std::numeric_limits<float>::infinity();
+    auto empty_node = [&]() {
+        ljd::DNode4 nd{};
+        for (int k = 0; k < 4; k++) { nd.lox[k] = nd.loy[k] = nd.loz[k] = inf; nd.hix[k] = nd.hiy[k] = nd.hiz[k] = -inf; nd.child[k] = 0; }
+        return nd;
+    };
+    if (n == 0) { nodes.push_back(empty_node()); depth_out = 1; return; }
     Builder b{prims, {}, {}, {}, max_leaf, max_depth};
     b.order.resize(n); b.centroid.resize(3 * (size_t)n);
     for (int i = 0; i < n; i++) { b.order[i] = i; for (int k = 0; k < 3; k++) b.centroid[3 * i + k] = 0.5f * (prims[i].lo[k] + prims[i].hi[k]); }
     b.tmp.reserve(2 * (size_t)n);
-    int root = b.build(0, n, 0);
+    const int root = b.build(0, n, 0);
     // Leaves hold at most 8 primitives (3-bit count in the child code); beyond the depth cap the builder keeps
     // splitting until that holds, and the caller checks the resulting depth against its traversal stack.
     if ((long long)n * 8 >= (1ll << 30)) throw LjError(LJ_ERR_UNSUPPORTED, "too many primitives for the 30-bit leaf code");
     leaf_order = b.order;
-    // breadth-first numbering of the inner nodes; leaves are folded into their parent's record
-    std::vector<int> bfs;  // TmpNode ids of inner nodes in output order
-    std::vector<int> out_index(b.tmp.size(), -1);
     auto is_leaf = [&](int id) { return b.tmp[id].left < 0; };
+    auto set_child = [&](ljd::DNode4 &nd, int k, int id, int code) {
+        const Box &bx = b.tmp[id].box;
+        nd.lox[k] = bx.lo[0]; nd.loy[k] = bx.lo[1]; nd.loz[k] = bx.lo[2];
+        nd.hix[k] = bx.hi[0]; nd.hiy[k] = bx.hi[1]; nd.hiz[k] = bx.hi[2];
+        nd.child[k] = code;
+    };
+    auto leaf_code = [&](int id) { return ~(b.tmp[id].first * 8 + b.tmp[id].count - 1); };
     if (is_leaf(root)) {
-        ljd::DNode nd{};
-        memcpy(nd.lo0, b.tmp[root].box.lo, 12); memcpy(nd.hi0, b.tmp[root].box.hi, 12);
-        nd.c0 = ~(b.tmp[root].first * 8 + b.tmp[root].count - 1); nd.n0 = b.tmp[root].count;
-        empty_child(nd.lo1, nd.hi1); nd.c1 = -1; nd.n1 = 0;
+        ljd::DNode4 nd = empty_node();
+        set_child(nd, 0, root, leaf_code(root));
         nodes.push_back(nd); depth_out = 1;
         return;
     }
-    bfs.push_back(root); out_index[root] = 0;
-    for (size_t h = 0; h < bfs.size(); h++) {
-        const TmpNode &t = b.tmp[bfs[h]];
-        for (int c : {t.left, t.right}) if (!is_leaf(c)) { out_index[c] = (int)bfs.size(); bfs.push_back(c); }
+    // collapse: a wide node starts from the two children of a binary node and opens its largest inner child until it
+    // has four; breadth-first numbering of the wide nodes
+    struct Wide { int kids[4]; int n; int depth; };
+    std::vector<Wide> wide;
+    std::vector<int> wide_of(b.tmp.size(), -1);  // binary node id -> wide node index (for the roots of wide nodes)
+    std::vector<int> queue{root};
+    wide_of[root] = 0;
+    std::vector<int> qdepth{1};
+    for (size_t h = 0; h < queue.size(); h++) {
+        const TmpNode &t = b.tmp[queue[h]];
+        Wide w; w.kids[0] = t.left; w.kids[1] = t.right; w.n = 2; w.depth = qdepth[h];
+        while (w.n < 4) {
+            int pick = -1; float area = -1.0f;
+            for (int k = 0; k < w.n; k++) if (!is_leaf(w.kids[k])) { const float a = b.tmp[w.kids[k]].box.half_area(); if (a > area) { area = a; pick = k; } }
+            if (pick < 0) break;
+            const TmpNode &c = b.tmp[w.kids[pick]];
+            w.kids[pick] = c.left; w.kids[w.n++] = c.right;
+        }
+        for (int k = 0; k < w.n; k++) if (!is_leaf(w.kids[k])) { wide_of[w.kids[k]] = (int)queue.size(); queue.push_back(w.kids[k]); qdepth.push_back(w.depth + 1); }
+        wide.push_back(w);
+        depth_out = std::max(depth_out, w.depth);
     }
-    nodes.resize(bfs.size());
-    for (size_t h = 0; h < bfs.size(); h++) {
-        const TmpNode &t = b.tmp[bfs[h]];
-        ljd::DNode nd{};
-        const TmpNode &L = b.tmp[t.left], &R = b.tmp[t.right];
-        memcpy(nd.lo0, L.box.lo, 12); memcpy(nd.hi0, L.box.hi, 12);
-        memcpy(nd.lo1, R.box.lo, 12); memcpy(nd.hi1, R.box.hi, 12);
-        if (is_leaf(t.left)) { nd.c0 = ~(L.first * 8 + L.count - 1); nd.n0 = L.count; } else { nd.c0 = out_index[t.left]; nd.n0 = 0; }
-        if (is_leaf(t.right)) { nd.c1 = ~(R.first * 8 + R.count - 1); nd.n1 = R.count; } else { nd.c1 = out_index[t.right]; nd.n1 = 0; }
+    nodes.resize(wide.size());
+    for (size_t h = 0; h < wide.size(); h++) {
+        ljd::DNode4 nd = empty_node();
+        for (int k = 0; k < wide[h].n; k++) { const int id = wide[h].kids[k]; set_child(nd, k, id, is_leaf(id) ? leaf_code(id) : wide_of[id]); }
         nodes[h] = nd;
-        depth_out = std::max(depth_out, t.depth + 1);
     }
 }
 

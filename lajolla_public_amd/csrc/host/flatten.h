@@ -11,7 +11,7 @@ namespace lj {
 
 struct FlatScene {
     ljd::DCamera cam{};
-    std::vector<ljd::DNode> nodes;
+    std::vector<ljd::DNode4> nodes;
     std::vector<ljd::DPrim> leaf_prims;
     std::vector<ljd::DPrimShade> prims;
     std::vector<ljd::DSphere> spheres;
@@ -36,9 +36,10 @@ struct FlatScene {
 // Throws LjError(LJ_ERR_UNSUPPORTED) for variant alternatives the device path does not implement.
 FlatScene flatten_scene(const LjSceneDesc &d);
 
-// bvh.cpp — binned-SAH BVH2 over padded float boxes; fills nodes (breadth-first) and leaf order.
+// bvh.cpp — binned-SAH tree over padded float boxes, collapsed to a BVH4; fills nodes (breadth-first) and leaf order.
+// depth_out = number of inner (wide) levels; a traversal needs at most 3 * depth_out stack entries.
 struct BuildPrim { float lo[3], hi[3]; };
 void build_bvh(const std::vector<BuildPrim> &prims, int max_leaf, int max_depth,
-               std::vector<ljd::DNode> &nodes, std::vector<int> &leaf_order, int &depth_out);
+               std::vector<ljd::DNode4> &nodes, std::vector<int> &leaf_order, int &depth_out);
 
 } // namespace lj

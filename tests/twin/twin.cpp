@@ -19,15 +19,14 @@ namespace {
 
 struct HostMem {
     const DScene &sc;
-    int stack[64];
+    int stack[192];
     mutable unsigned long long n_nodes = 0, n_prims = 0;
     explicit HostMem(const DScene &s) : sc(s) {}
-    DNode node(int i) const { n_nodes++; return sc.nodes[i]; }
+    DNode4 node(int i) const { n_nodes++; return sc.nodes[i]; }
     DPrim prim(int i) const { n_prims++; return sc.leaf_prims[i]; }
     const DSphere &sphere(int s) const { return sc.spheres[s]; }
     void push(int sp, int v) { stack[sp] = v; }
     int pop(int sp) const { return stack[sp]; }
-    int max_stack() const { return 64; }
 };
 
 // traversal work counters (debugging aid): [shadow rays, shadow nodes, shadow prims, ext rays, ext nodes, ext prims]
