@@ -13,13 +13,13 @@
 #include <vector>
 
 namespace ljd {
-struct ExtendConfig { int stack; int spill_levels; int lds_nodes; int lds_prims; size_t smem; uint32_t refill_min, min_descending; };
+struct ExtendConfig { int stack; int spill_levels; int lds_nodes; int lds_prims; int resident; size_t smem; uint32_t refill_min, min_descending; };
 struct ShadeConfig { uint32_t prims_bytes, materials_bytes, lights_bytes, light_cdf_bytes, light_tris_bytes, light_tri_cdf_bytes, stage_prims; size_t smem; };
 ShadeConfig shade_config(size_t n_prims, size_t n_materials, size_t n_lights, size_t n_light_tris, size_t n_light_tri_cdf);
 ExtendConfig extend_config(int n_nodes, int n_prims, int bvh_depth);
 int max_stack_depth();
-void launch_extend(const DScene &sc, const DQueue &q, const DBlockState *blocks, uint32_t n_blocks, uint32_t seg, const ExtendConfig &cfg, int *spill, hipStream_t s);
-void launch_shade(const DScene &sc, const DPass &pass, const DQueue &q, DBlockState *blocks, uint32_t n_blocks, uint32_t seg, const ShadeConfig &cfg, hipStream_t s);
+void launch_extend(const DScene &sc, const DQueue &q, const DBlockState *blocks, uint32_t grid, uint32_t seg, uint32_t *work, const uint32_t *chunk_list, uint32_t parity, const ExtendConfig &cfg, int *spill, unsigned long long *stats, hipStream_t s);
+void launch_shade(const DScene &sc, const DPass &pass, const DQueue &q, DBlockState *blocks, uint32_t n_blocks, uint32_t seg, const ShadeConfig &cfg, uint32_t *work, uint32_t *chunk_list, uint32_t parity, hipStream_t s);
 void launch_resolve(const DPass &pass, uint32_t n_pixels, float *rgb, hipStream_t s);
 void launch_trace_rays(const DScene &sc, const void *rays, long long n, void *hits, unsigned char *occ, const ExtendConfig &cfg, int *spill, int grid, hipStream_t s);
 }
@@ -55,6 +55,7 @@ struct lj_context {
     int n_cus = 256;
     // workspace, grown on demand and reused across renders
     DevBuf queue_mem; uint32_t queue_capacity = 0;
+    DevBuf chunk_counter, chunk_list;  // the extend kernel's work counters and the two lists of live queue chunks
     DevBuf spill;  // overflow levels of the traversal stacks: spill_levels x (grid * 256) ints
     DevBuf blocks, sample_rgb, pixel_list, frame;
     ljd::DBlockState *blocks_host = nullptr;  // pinned, kMaxBlocks entries
@@ -114,7 +115,8 @@ RenderPlan make_plan(const lj_scene *sc, const LjRenderArgs *a) {
     if (p.spp <= 0) throw LjError(LJ_ERR_INVALID_ARG, "samples per pixel must be positive");
     p.seed = (a && a->seed) ? a->seed : 0x853c49e6748fea9bULL;
     p.max_depth = (a && a->max_depth != INT32_MIN) ? a->max_depth : sc->flat.max_depth;
-    p.pool = (a && a->pool_paths) ? a->pool_paths : (1u << 21);
+    p.pool = (a && a->pool_paths) ? a->pool_paths : (1u << 24);  // 16 M paths in flight = 2 GiB of queue records: long per-wave
+    // slices keep the extend kernel's lanes refilled (a wave's drain phase is amortised over ~2 k paths)
     p.pool = std::max<uint32_t>(p.pool, 4096);
     if (a && a->rng_mode != LJ_RNG_SAMPLE) throw LjError(LJ_ERR_UNSUPPORTED, "only LJ_RNG_SAMPLE exists on the device (a per-tile sequential stream cannot be parallelised, SURVEY §0.2)");
     int rank = a ? a->rank : 0, world = (a && a->world_size > 0) ? a->world_size : 1;
@@ -156,11 +158,29 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
     // queue geometry: n_blocks workgroups x seg slots; workgroup b owns slots [b*seg, (b+1)*seg)
     const uint64_t pass_samples_max = pix_per_pass * (uint64_t)plan.spp;
     uint32_t pool = (uint32_t)std::min<uint64_t>(plan.pool, std::max<uint64_t>(pass_samples_max, 256));
-    uint32_t n_blocks = std::min<uint32_t>(kMaxBlocks, std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)ctx->n_cus * 8, pool / 256)));
+    uint32_t blocks_per_cu = 8;
+    if (const char *e = getenv("LJ_TUNE_BLOCKS_PER_CU")) blocks_per_cu = (uint32_t)std::max(1, atoi(e));
+    uint32_t n_blocks = std::min<uint32_t>(kMaxBlocks, std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)ctx->n_cus * blocks_per_cu, pool / 256)));
     uint32_t seg = ((pool + n_blocks - 1) / n_blocks + 255u) & ~255u;
     const uint32_t n_slots = n_blocks * seg;
     ensure_queues(ctx, n_slots);
-    int *spill = ensure_spill(ctx, sc->ecfg.spill_levels, n_blocks);
+    // extend: persistent workgroups (as many as fit the GPU at once) that draw 256-slot chunks of the queue
+    uint32_t ext_per_cu = 4;
+    if (const char *e = getenv("LJ_TUNE_EXTEND_BLOCKS_PER_CU")) ext_per_cu = (uint32_t)std::max(1, atoi(e));
+    const uint32_t n_chunks = n_slots / 256u;
+    const uint32_t ext_grid = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)ctx->n_cus * ext_per_cu, (n_chunks + 3) / 4));
+    int *spill = ensure_spill(ctx, sc->ecfg.spill_levels, ext_grid);
+    // work[0] = the extend kernel's draw counter, work[1 + parity] = number of listed chunks; two chunk lists, used
+    // alternately, so that a shade launch can append to one while nothing reads it
+    if (!ctx->chunk_counter.p) ctx->chunk_counter.alloc(64);
+    if (ctx->chunk_list.bytes < (size_t)n_chunks * 8) ctx->chunk_list.alloc((size_t)n_chunks * 8);
+    uint32_t *work = (uint32_t *)ctx->chunk_counter.p;
+    uint32_t *chunk_lists[2] = {(uint32_t *)ctx->chunk_list.p, (uint32_t *)ctx->chunk_list.p + n_chunks};
+    uint32_t parity = 0;
+    // developer instrumentation of the extend kernel (utilisation counters printed to stderr); off unless asked for
+    unsigned long long *xstats = nullptr;
+    DevBuf xstats_buf;
+    if (getenv("LJ_EXTEND_STATS")) { xstats_buf.alloc(64); HIP_CHECK(hipMemsetAsync(xstats_buf.p, 0, 64, stream)); xstats = (unsigned long long *)xstats_buf.p; }
     ljd::DQueue q = carve_queue(ctx->queue_mem.p, ctx->queue_capacity);
     if (ctx->sample_rgb.bytes < pass_samples_max * 12) ctx->sample_rgb.alloc(pass_samples_max * 12);
     if (ctx->pixel_list.bytes < n_pix * 4) ctx->pixel_list.alloc(n_pix * 4);
@@ -186,15 +206,18 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
             HIP_CHECK(hipMemcpyAsync(dblocks, ctx->blocks_host, sizeof(ljd::DBlockState) * n_blocks, hipMemcpyHostToDevice, stream));
         }
         // step 0 is a shade over empty segments: it only generates camera rays
-        ljd::launch_shade(ds, pass, q, dblocks, n_blocks, seg, sc->scfg, stream);
+        HIP_CHECK(hipMemsetAsync(work, 0, 64, stream));
+        parity = 0;
+        ljd::launch_shade(ds, pass, q, dblocks, n_blocks, seg, sc->scfg, work, chunk_lists[parity], parity, stream);
         bool done = false;
         for (int guard = 0; guard < (1 << 20) && !done; guard++) {
             const int batch = 8;  // steps per host round trip; all per-step state lives on the device
             for (int b = 0; b < batch; b++) {
                 if (timing) HIP_CHECK(hipEventRecord(ctx->ev_k0, stream));
-                ljd::launch_extend(ds, q, dblocks, n_blocks, seg, sc->ecfg, spill, stream);
+                ljd::launch_extend(ds, q, dblocks, ext_grid, seg, work, chunk_lists[parity], parity, sc->ecfg, spill, xstats, stream);
                 if (timing) HIP_CHECK(hipEventRecord(ctx->ev_k1, stream));
-                ljd::launch_shade(ds, pass, q, dblocks, n_blocks, seg, sc->scfg, stream);
+                parity ^= 1u;
+                ljd::launch_shade(ds, pass, q, dblocks, n_blocks, seg, sc->scfg, work, chunk_lists[parity], parity, stream);
                 if (timing) {
                     HIP_CHECK(hipEventRecord(ctx->ev_end, stream));
                     HIP_CHECK(hipEventSynchronize(ctx->ev_end));
@@ -234,6 +257,12 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
     HIP_CHECK(hipEventSynchronize(ctx->ev_end));
     float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
     st.render_ms = ms; st.extend_ms = extend_ms; st.shade_ms = shade_ms;
+    if (xstats) {
+        unsigned long long h[8];
+        HIP_CHECK(hipMemcpy(h, xstats, 64, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[extend stats] rays %llu | outer iters %llu busy lanes %.1f%% | node steps %llu (%.2f/ray) lane use %.1f%% | prim rounds %llu (%.2f tests/ray) lane use %.1f%% | refills %llu\n",
+                h[7], h[0], 100.0 * h[1] / (64.0 * h[0]), h[2], (double)h[3] / h[7], 100.0 * h[3] / (64.0 * h[2]), h[4], (double)h[5] / h[7], 100.0 * h[5] / (64.0 * h[4]), h[6]);
+    }
     st.queue_bytes = st.extend_bytes + st.shade_bytes;
 }
 

@@ -84,6 +84,7 @@ __device__ __forceinline__ TreeView stage_tree(const DScene &sc, int stack, int 
     return tv;
 }
 
+constexpr uint32_t kChunk = 256;   // queue slots a wave draws at a time (segments are multiples of it)
 constexpr int kDone = 0x7fffffff;  // "no more work for this ray" marker in `cur`
 
 struct LaneTrav {
@@ -118,17 +119,22 @@ __device__ __forceinline__ void csw(float &ta, int &ca, float &tb, int &cb) {  /
     ta = t0; tb = t1; ca = c0; cb = c1;
 }
 
-// one inner-node step: slab-test the four children, continue with the nearest one that is hit, push the others far-first
+// one inner-node step: slab-test the four children, continue with the nearest one that is hit, push the others far-first.
+// RESIDENT: the whole tree and every stack level are in LDS (small scenes) — the step is then free of branches: the
+// three pushes store unconditionally and advance `sp` only for a hit, and the pop candidate is fetched with the node.
+template <bool RESIDENT>
 __device__ __forceinline__ void trav_node_step(const TreeView &tv, LaneTrav &L) {
     v4f nx, ny, nz, fx, fy, fz, ch;
     const int i = L.cur;
-    if (i < tv.n_lnodes) {
+    int popped = kDone;
+    if (RESIDENT || i < tv.n_lnodes) {
         const LJ_LDS char *b = tv.lnodes + (uint32_t)i * 16u;
         const uint32_t S = tv.qstride;
         nx = *(const LJ_LDS v4f *)(b + L.nqx * S); fx = *(const LJ_LDS v4f *)(b + (3u - L.nqx) * S);
         ny = *(const LJ_LDS v4f *)(b + L.nqy * S); fy = *(const LJ_LDS v4f *)(b + (5u - L.nqy) * S);
         nz = *(const LJ_LDS v4f *)(b + L.nqz * S); fz = *(const LJ_LDS v4f *)(b + (7u - L.nqz) * S);
         ch = *(const LJ_LDS v4f *)(b + 6u * S);
+        if (RESIDENT) popped = tv.stack[(L.sp > 0 ? L.sp - 1 : 0) * kBlock];
     } else {
         const char *g = tv.gnodes;
         const uint32_t o = (uint32_t)i * 128u;
@@ -153,13 +159,24 @@ __device__ __forceinline__ void trav_node_step(const TreeView &tv, LaneTrav &L) 
     csw(t0[0], c[0], t0[1], c[1]); csw(t0[2], c[2], t0[3], c[3]);
     csw(t0[0], c[0], t0[2], c[2]); csw(t0[1], c[1], t0[3], c[3]);
     csw(t0[1], c[1], t0[2], c[2]);
-    if (t0[3] < inf) trav_push(tv, L, c[3]);
-    if (t0[2] < inf) trav_push(tv, L, c[2]);
-    if (t0[1] < inf) trav_push(tv, L, c[1]);
-    L.cur = (t0[0] < inf) ? c[0] : trav_pop(tv, L);
+    if (RESIDENT) {
+        const int sp0 = L.sp;
+        tv.stack[L.sp * kBlock] = c[3]; L.sp += (t0[3] < inf) ? 1 : 0;   // misses sort last: a slot written for a miss is
+        tv.stack[L.sp * kBlock] = c[2]; L.sp += (t0[2] < inf) ? 1 : 0;   // overwritten by the next store or never read
+        tv.stack[L.sp * kBlock] = c[1]; L.sp += (t0[1] < inf) ? 1 : 0;
+        const bool any = t0[0] < inf;
+        L.cur = any ? c[0] : (sp0 > 0 ? popped : kDone);
+        L.sp = any ? L.sp : (sp0 > 0 ? sp0 - 1 : 0);
+    } else {
+        if (t0[3] < inf) trav_push(tv, L, c[3]);
+        if (t0[2] < inf) trav_push(tv, L, c[2]);
+        if (t0[1] < inf) trav_push(tv, L, c[1]);
+        L.cur = (t0[0] < inf) ? c[0] : trav_pop(tv, L);
+    }
 }
 
 // one leaf: up to 8 primitives
+template <bool RESIDENT>
 __device__ __forceinline__ void trav_leaf_step(const TreeView &tv, LaneTrav &L, const bool ANY_HIT) {
     const int code = ~L.cur;
     const int first = code >> 3, count = (code & 7) + 1;
@@ -167,7 +184,7 @@ __device__ __forceinline__ void trav_leaf_step(const TreeView &tv, LaneTrav &L, 
     for (int k = 0; k < count && !stop; k++) {
         const int pi = first + k;
         v4f p0, p1, p2;
-        if (pi < tv.n_lprims) { const int S = tv.prim_stride; p0 = tv.lprims[pi]; p1 = tv.lprims[S + pi]; p2 = tv.lprims[2 * S + pi]; }
+        if (RESIDENT || pi < tv.n_lprims) { const int S = tv.prim_stride; p0 = tv.lprims[pi]; p1 = tv.lprims[S + pi]; p2 = tv.lprims[2 * S + pi]; }
         else { p0 = tv.gprims[3 * pi]; p1 = tv.gprims[3 * pi + 1]; p2 = tv.gprims[3 * pi + 2]; }
         const int gprim = __float_as_int(p0.w), kind = __float_as_int(p1.w);
         if (kind == 0) {
@@ -189,25 +206,46 @@ __device__ __forceinline__ void trav_leaf_step(const TreeView &tv, LaneTrav &L, 
     L.cur = stop ? kDone : trav_pop(tv, L);
 }
 
-__global__ void __launch_bounds__(kBlock, 4) k_extend(DScene sc, DQueue q, const DBlockState *blocks, uint32_t seg, int stack, int lds_nodes, int lds_prims, int *spill, uint32_t refill_min, uint32_t min_descending) {
+// STATS: developer instrumentation (LJ_EXTEND_STATS=1): wave-level step counts and the lanes active in them, summed into
+// stats[0..7] = {outer iterations, sum of busy lanes, node steps, lanes in node steps, leaf prim rounds, lanes in them,
+// refills, rays}.  The production instantiation carries none of it.
+template <bool STATS, bool RESIDENT>
+__global__ void __launch_bounds__(kBlock, 4) k_extend(DScene sc, DQueue q, const DBlockState *blocks, uint32_t seg, uint32_t *work, const uint32_t *chunk_list, uint32_t parity, int stack, int lds_nodes, int lds_prims, int *spill, uint32_t refill_min, uint32_t min_descending, unsigned long long *stats) {
+    unsigned long long st_outer = 0, st_busy = 0, st_nodes = 0, st_node_lanes = 0, st_leaf = 0, st_leaf_lanes = 0, st_refill = 0, st_rays = 0;
     const TreeView tv = stage_tree(sc, stack, lds_nodes, lds_prims, spill, gridDim.x * kBlock, blockIdx.x * kBlock + threadIdx.x);
-    // workgroup b traces segment b; its four waves split the live front of the segment into contiguous slices
-    const uint32_t count = blocks[blockIdx.x].count, seg_base = blockIdx.x * seg;
-    uint32_t slice = ((count + (kBlock / 64) - 1) / (kBlock / 64) + 63u) & ~63u;
-    uint32_t next = (threadIdx.x >> 6) * slice;         // wave-uniform
-    uint32_t end = next + slice; if (end > count) end = count;
-    if (next > count) next = count;
-    next += seg_base; end += seg_base;
+    // Persistent waves: the shade launch before this one listed the chunks (kChunk queue slots inside one of its
+    // segments) that hold live paths; every wave draws its next chunk from one grid-wide counter, so the launch stays
+    // balanced whatever the rays cost.  work[0] = draw counter, work[1 + parity] = length of this step's list.
+    const uint32_t n_chunks = work[1 + parity];
+    if (blockIdx.x == 0 && threadIdx.x == 0) work[1 + (parity ^ 1u)] = 0u;   // the next shade launch appends to the other list
+    uint32_t *chunk_counter = work;
+    const bool leader = (threadIdx.x & 63u) == 0u;
+    uint32_t pre = 0;                       // prefetched list position (valid in the wave's first lane)
+    if (leader) pre = atomicAdd(chunk_counter, 1u);
+    uint32_t next = 0, end = 0;             // live slots of the open chunk (wave-uniform)
+    bool exhausted = false;
     // per-lane state: phase 0 = shadow ray (any hit), phase 1 = extension ray (closest hit)
     bool busy = false; int phase = 0; uint32_t path = 0; uint32_t flags = 0; int vis = 0;
     float edx = 0, edy = 0, edz = 0;
     LaneTrav L; L.cur = kDone; L.sp = 0;
     for (;;) {
-        // ---- refill: lanes without a ray take the next paths of the slice (kept wave-complete: no early exits above)
+        if (next == end && !exhausted) {    // open the prefetched chunk and draw the one after it
+            const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)pre);
+            if (c >= n_chunks) exhausted = true;
+            else {
+                const uint32_t slot0 = chunk_list[c] * kChunk, b = slot0 / seg, off = slot0 - b * seg, cnt = blocks[b].count;
+                const uint32_t live = cnt > off ? (cnt - off < kChunk ? cnt - off : kChunk) : 0u;
+                next = slot0; end = slot0 + live;
+                if (leader) pre = atomicAdd(chunk_counter, 1u);
+                if (live == 0u) continue;
+            }
+        }
+        // ---- refill: lanes without a ray take the next paths of the chunk (kept wave-complete: no early exits above)
         const unsigned long long idle = __ballot(!busy);
         const uint32_t n_idle = (uint32_t)__popcll(idle);
         const uint32_t left = end - next;
         if (left > 0 && (n_idle >= refill_min || n_idle == 64u)) {
+            if (STATS) st_refill++;
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
             const bool take = !busy && rank < left;
             if (take) {
@@ -227,7 +265,8 @@ __global__ void __launch_bounds__(kBlock, 4) k_extend(DScene sc, DQueue q, const
             }
             next += n_idle < left ? n_idle : left;
         }
-        if (__ballot(busy) == 0ull) { if (end - next == 0u) break; else continue; }
+        if (__ballot(busy) == 0ull) { if (exhausted && next == end) break; else continue; }
+        if (STATS) { st_outer++; st_busy += __popcll(__ballot(busy)); }
         // ---- while-while traversal: descend inner nodes until every busy lane sits on a leaf (or is done) ...
         // (lanes that reach a leaf wait here; once only a few lanes are still descending, everybody moves on to the
         // leaf phase and the stragglers resume in the next round)
@@ -237,11 +276,19 @@ __global__ void __launch_bounds__(kBlock, 4) k_extend(DScene sc, DQueue q, const
             if (dm == 0ull) break;
             // only hand over to the leaf phase if some lane actually has a leaf to test (otherwise no progress is made)
             if ((uint32_t)__popcll(dm) < min_descending && __ballot(busy && L.cur < 0) != 0ull) break;
-            if (descending) trav_node_step(tv, L);
+            if (STATS) { st_nodes++; st_node_lanes += __popcll(dm); }
+            if (descending) trav_node_step<RESIDENT>(tv, L);
+        }
+        if (STATS) {
+            const bool at_leaf = busy && L.cur < 0;
+            int cnt = at_leaf ? ((~L.cur) & 7) + 1 : 0, mx = cnt, sum = cnt;
+            for (int o = 32; o > 0; o >>= 1) { mx = max(mx, __shfl_xor(mx, o, 64)); sum += __shfl_xor(sum, o, 64); }
+            st_leaf += mx; st_leaf_lanes += sum;
         }
         // ... then all of them test their leaf together
-        if (busy && L.cur < 0) trav_leaf_step(tv, L, phase == 0);
+        if (busy && L.cur < 0) trav_leaf_step<RESIDENT>(tv, L, phase == 0);
         // ---- ray finished?
+        if (STATS) st_rays += __popcll(__ballot(busy && L.cur == kDone));
         if (busy && L.cur == kDone) {
             if (phase == 0) {
                 vis = (L.best.gprim < 0) ? HIT_VIS_BIT : 0;
@@ -256,6 +303,10 @@ __global__ void __launch_bounds__(kBlock, 4) k_extend(DScene sc, DQueue q, const
                 busy = false;
             }
         }
+    }
+    if (STATS && (threadIdx.x & 63) == 0) {
+        atomicAdd(&stats[0], st_outer); atomicAdd(&stats[1], st_busy); atomicAdd(&stats[2], st_nodes); atomicAdd(&stats[3], st_node_lanes);
+        atomicAdd(&stats[4], st_leaf); atomicAdd(&stats[5], st_leaf_lanes); atomicAdd(&stats[6], st_refill); atomicAdd(&stats[7], st_rays);
     }
 }
 
@@ -275,7 +326,9 @@ __device__ __forceinline__ void lds_copy16(void *dst, const void *src, uint32_t 
     for (uint32_t i = threadIdx.x; i < bytes / 16; i += kBlock) d4[i] = s4[i];
 }
 
-__global__ void __launch_bounds__(kBlock, 4) k_shade(DScene sc, DPass pass, DQueue q, DBlockState *blocks, uint32_t seg, ShadeStage stg) {
+__global__ void __launch_bounds__(kBlock, 4) k_shade(DScene sc, DPass pass, DQueue q, DBlockState *blocks, uint32_t seg, ShadeStage stg, uint32_t *work, uint32_t *chunk_list, uint32_t parity) {
+    __shared__ uint32_t s_list_base;
+    if (blockIdx.x == 0 && threadIdx.x == 0) work[0] = 0u;   // the extend launch that follows draws its chunks from it
     __shared__ uint32_t s_wcnt[2][kBlock / 64];
     __shared__ unsigned long long s_cnt[5];
     {
@@ -333,6 +386,11 @@ __global__ void __launch_bounds__(kBlock, 4) k_shade(DScene sc, DPass pass, DQue
         atomicAdd(&s_cnt[3], (unsigned long long)dn);
     }
     __syncthreads();
+    // list this segment's live chunks for the extend launch (one atomic per workgroup)
+    const uint32_t live_chunks = (out + n_new + kChunk - 1) / kChunk;
+    if (threadIdx.x == 0) s_list_base = live_chunks ? atomicAdd(&work[1 + parity], live_chunks) : 0u;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < live_chunks; i += kBlock) chunk_list[s_list_base + i] = blockIdx.x * (seg / kChunk) + i;
     if (threadIdx.x == 0) {
         bs.next_sample = next_sample + n_new;
         bs.count = out + n_new;
@@ -368,8 +426,8 @@ __global__ void __launch_bounds__(kBlock) k_trace_rays(DScene sc, const RayIO *r
         L.ray.dx = rays[i].dir[0]; L.ray.dy = rays[i].dir[1]; L.ray.dz = rays[i].dir[2];
         trav_begin(L, rays[i].tnear, rays[i].tfar);
         while (L.cur != kDone) {
-            while (L.cur >= 0 && L.cur != kDone) trav_node_step(tv, L);
-            if (L.cur < 0) trav_leaf_step(tv, L, occ != nullptr);
+            while (L.cur >= 0 && L.cur != kDone) trav_node_step<false>(tv, L);
+            if (L.cur < 0) trav_leaf_step<false>(tv, L, occ != nullptr);
         }
         if (occ) occ[i] = L.best.gprim >= 0 ? 1 : 0;
         else {
@@ -388,7 +446,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_rays(DScene sc, const RayIO *r
 // lane's stack live in LDS (1 KiB per level and workgroup); deeper levels — rare — go to a global overflow buffer.
 // LDS per 256-thread workgroup = stack * 1 KiB + staged nodes * 112 B + staged prims * 48 B; four workgroups share a
 // CU's 160 KiB, so the budget per workgroup is 40 KiB.
-struct ExtendConfig { int stack; int spill_levels; int lds_nodes; int lds_prims; size_t smem; uint32_t refill_min, min_descending; };
+struct ExtendConfig { int stack; int spill_levels; int lds_nodes; int lds_prims; int resident; size_t smem; uint32_t refill_min, min_descending; };
 
 ExtendConfig extend_config(int n_nodes, int n_prims, int bvh_depth) {
     ExtendConfig c;
@@ -401,8 +459,13 @@ ExtendConfig extend_config(int n_nodes, int n_prims, int bvh_depth) {
     int max_nodes = (budget - c.lds_prims * 48) / 112;
     if (max_nodes < 0) max_nodes = 0;
     c.lds_nodes = n_nodes < max_nodes ? n_nodes : max_nodes;
+    // whole tree, all primitives and every stack level (+1: the branch-free pushes store one slot ahead) in LDS
+    c.resident = (c.lds_nodes == n_nodes && c.lds_prims == n_prims && c.spill_levels == 0 && c.stack + 1 <= 16) ? 1 : 0;
+    if (c.resident) c.stack += 1;
     c.smem = (size_t)c.stack * kBlock * 4 + (size_t)c.lds_nodes * 112 + (size_t)c.lds_prims * 48;
-    c.refill_min = 8; c.min_descending = 1;  // tuned on cbox / MI355X (tools/tune.sh)
+    // tuned on MI355X (tools/tune.sh): when the tree is LDS-resident a node step is cheap and waiting for the last
+    // descending lane costs little; with nodes in L2 the leaf phase starts once fewer than 16 lanes still descend
+    c.refill_min = 8; c.min_descending = (n_nodes <= c.lds_nodes) ? 1 : 16;
     return c;
 }
 int max_stack_depth() { return 40; }  // inner levels; the builder's own cap is 38
@@ -425,14 +488,18 @@ ShadeConfig shade_config(size_t n_prims, size_t n_materials, size_t n_lights, si
     return c;
 }
 
-void launch_extend(const DScene &sc, const DQueue &q, const DBlockState *blocks, uint32_t n_blocks, uint32_t seg, const ExtendConfig &cfg, int *spill, hipStream_t s) {
-    hipLaunchKernelGGL(k_extend, dim3(n_blocks), dim3(kBlock), cfg.smem, s, sc, q, blocks, seg, cfg.stack, cfg.lds_nodes, cfg.lds_prims, spill, cfg.refill_min, cfg.min_descending);
+void launch_extend(const DScene &sc, const DQueue &q, const DBlockState *blocks, uint32_t grid, uint32_t seg, uint32_t *work, const uint32_t *chunk_list, uint32_t parity, const ExtendConfig &cfg, int *spill, unsigned long long *stats, hipStream_t s) {
+    auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), cfg.smem, s, sc, q, blocks, seg, work, chunk_list, parity, cfg.stack, cfg.lds_nodes, cfg.lds_prims, spill, cfg.refill_min, cfg.min_descending, stats);
+    };
+    if (stats) { if (cfg.resident) launch(k_extend<true, true>); else launch(k_extend<true, false>); }
+    else { if (cfg.resident) launch(k_extend<false, true>); else launch(k_extend<false, false>); }
 }
-void launch_shade(const DScene &sc, const DPass &pass, const DQueue &q, DBlockState *blocks, uint32_t n_blocks, uint32_t seg, const ShadeConfig &cfg, hipStream_t s) {
+void launch_shade(const DScene &sc, const DPass &pass, const DQueue &q, DBlockState *blocks, uint32_t n_blocks, uint32_t seg, const ShadeConfig &cfg, uint32_t *work, uint32_t *chunk_list, uint32_t parity, hipStream_t s) {
     ShadeStage st;
     st.prims_bytes = cfg.prims_bytes; st.materials_bytes = cfg.materials_bytes; st.lights_bytes = cfg.lights_bytes; st.light_cdf_bytes = cfg.light_cdf_bytes;
     st.light_tris_bytes = cfg.light_tris_bytes; st.light_tri_cdf_bytes = cfg.light_tri_cdf_bytes; st.stage_prims = cfg.stage_prims;
-    hipLaunchKernelGGL(k_shade, dim3(n_blocks), dim3(kBlock), cfg.smem, s, sc, pass, q, blocks, seg, st);
+    hipLaunchKernelGGL(k_shade, dim3(n_blocks), dim3(kBlock), cfg.smem, s, sc, pass, q, blocks, seg, st, work, chunk_list, parity);
 }
 void launch_resolve(const DPass &pass, uint32_t n_pixels, float *rgb, hipStream_t s) {
     const uint32_t waves_per_block = kBlock / 64;
