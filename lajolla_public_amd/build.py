@@ -69,7 +69,7 @@ def build_product(verbose=True):
         objs.append(o)
         if _stale(o, [s] + headers):
             jobs.append([_hipcc(), "-std=c++17", "-O3", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
-                         "-fno-gpu-rdc", "-c", s, "-o", o])
+                         "-fno-gpu-rdc"] + os.environ.get("LJ_EXTRA_HIPCC_FLAGS", "").split() + ["-c", s, "-o", o])
     if jobs:
         if verbose:
             print(f"[build] compiling {len(jobs)} translation unit(s) for {ARCH}", file=sys.stderr)

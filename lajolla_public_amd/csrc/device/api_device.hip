@@ -14,8 +14,9 @@
 
 namespace ljd {
 struct ExtendConfig { int stack; int spill_levels; int lds_nodes; int lds_prims; int resident; size_t smem; uint32_t refill_min, min_descending; };
-struct ShadeConfig { uint32_t prims_bytes, materials_bytes, lights_bytes, light_cdf_bytes, light_tris_bytes, light_tri_cdf_bytes, stage_prims; size_t smem; };
+struct ShadeConfig { uint32_t prims_bytes, materials_bytes, lights_bytes, light_cdf_bytes, light_tris_bytes, light_tri_cdf_bytes, stage_prims; int variant; size_t smem; };
 ShadeConfig shade_config(size_t n_prims, size_t n_materials, size_t n_lights, size_t n_light_tris, size_t n_light_tri_cdf);
+int shade_variant(uint32_t kinds, bool textured, bool envmap, bool sphere_lights);
 ExtendConfig extend_config(int n_nodes, int n_prims, int bvh_depth);
 int max_stack_depth();
 void launch_extend(const DScene &sc, const DQueue &q, const DBlockState *blocks, uint32_t grid, uint32_t seg, uint32_t *work, const uint32_t *chunk_list, uint32_t parity, const ExtendConfig &cfg, int *spill, unsigned long long *stats, hipStream_t s);
@@ -330,6 +331,13 @@ int lj_scene_upload(lj_context *ctx, const LjSceneDesc *desc, lj_scene **out) {
         if (const char *e = getenv("LJ_TUNE_REFILL")) sc->ecfg.refill_min = (uint32_t)atoi(e);
         if (const char *e = getenv("LJ_TUNE_MINDESC")) sc->ecfg.min_descending = (uint32_t)atoi(e);
         sc->scfg = ljd::shade_config(F.prims.size(), F.materials.size(), F.lights.size(), F.light_tris.size(), F.light_tri_cdf.size());
+        {   // which Material / Texture / Light alternatives the scene holds decides the shade kernel instantiation
+            uint32_t kinds = 0; bool textured = false, sphere_lights = false;
+            for (const auto &m : F.materials) { kinds |= 1u << m.kind; for (int t = 0; t < 12; t++) textured = textured || m.tex[t].kind != 0; }
+            for (const auto &l : F.lights) sphere_lights = sphere_lights || (l.kind == 0 && l.is_sphere);
+            sc->scfg.variant = ljd::shade_variant(kinds, textured, F.envmap_light_id >= 0, sphere_lights);
+            if (const char *e = getenv("LJ_TUNE_SHADE_VARIANT")) sc->scfg.variant = std::max(sc->scfg.variant, atoi(e));
+        }
         *out = sc.release();
     });
 }

@@ -8,6 +8,19 @@
 namespace ljd {
 
 // ------------------------------------------------------------------ textures (texture.h:123-154, mipmap.h:52-89)
+// Compile-time description of what a scene can contain.  The shade kernel is instantiated for a few feature sets
+// (kernels.hip) and the scene upload picks the smallest one that covers the scene: code for absent Material / Texture /
+// Light alternatives is not generated at all, which cuts registers, spills and instruction-cache pressure.
+// KINDS: bit k set = Material alternative k may occur.  TEXTURED: image / checkerboard textures may occur.
+// ENVMAP: an environment map light may occur.  SPHERE_LIGHTS: spherical area lights may occur.
+template <uint32_t KINDS, bool TEXTURED, bool ENVMAP, bool SPHERE_LIGHTS>
+struct ShadeFeat {
+    static constexpr uint32_t kinds = KINDS;
+    static constexpr bool textured = TEXTURED, envmap = ENVMAP, sphere_lights = SPHERE_LIGHTS;
+    static constexpr bool kind(int k) { return ((KINDS >> k) & 1u) != 0u; }
+};
+using FeatAll = ShadeFeat<0x1ffu, true, true, true>;
+
 LJ_HD f3 texel(const DScene &sc, const DImage &img, int level, int x, int y) {
     const DMipLevel lv = img.lv[level];
     const float *p = sc.texels + lv.offset + ((int64_t)y * lv.w + x) * img.channels;
@@ -37,8 +50,9 @@ LJ_HD f3 mip_lookup(const DScene &sc, const DImage &img, double u, double v, flo
     return mip_lookup_level(sc, img, u, v, img.levels - 1);
 }
 LJ_HD double modulod(double a, double b) { double r = fmod(a, b); return (r < 0.0) ? r + b : r; }
+template <class Ft = FeatAll>
 LJ_HD f3 eval_texture(const DScene &sc, const DTexture &t, bool spectrum, double u, double v, float footprint) {
-    if (t.kind == 0) return ld3(t.value);
+    if (!Ft::textured || t.kind == 0) return ld3(t.value);
     double lu = modulod(u * (double)t.uscale + (double)t.uoffset, 1.0), lv = modulod(v * (double)t.vscale + (double)t.voffset, 1.0);
     if (t.kind == 1) {
         const DImage &img = spectrum ? sc.images3[t.texture_id] : sc.images1[t.texture_id];
@@ -156,10 +170,11 @@ LJ_HD float sphere_one_minus_cos_max(float r, float dist_sq) {
     return s / (1.0f + sqrtf(fmaxf(0.0f, 1.0f - s)));
 }
 
+template <class Ft = FeatAll>
 LJ_HD LightSample sample_point_on_light(const DScene &sc, const DLight &L, f3 ref, float u0, float u1, float w) {
     LightSample ls;
-    if (L.kind == 0) {
-        if (!L.is_sphere) {  // triangle_mesh.inl:24-38
+    if (!Ft::envmap || L.kind == 0) {
+        if (!Ft::sphere_lights || !L.is_sphere) {  // triangle_mesh.inl:24-38
             int tri = sample_cdf(sc.light_tri_cdf + L.cdf_first, L.tri_count, w);
             const DLightTri &T = sc.light_tris[L.tri_first + tri];
             float a = sqrtf(clampf(u0, 0.0f, 1.0f));
@@ -214,9 +229,10 @@ LJ_HD void envmap_dir_to_uv(f3 local, float &u, float &v) {
     if (u < 0.0f) u += 1.0f;
 }
 
+template <class Ft = FeatAll>
 LJ_HD float pdf_point_on_light(const DScene &sc, const DLight &L, f3 pos, f3 nrm, f3 ref) {
-    if (L.kind == 0) {
-        if (!L.is_sphere) return 1.0f / L.total_area;  // triangle_mesh.inl:44-46
+    if (!Ft::envmap || L.kind == 0) {
+        if (!Ft::sphere_lights || !L.is_sphere) return 1.0f / L.total_area;  // triangle_mesh.inl:44-46
         f3 center = ld3(L.center); float r = L.radius;  // sphere.inl:210-230
         f3 dc_vec = ref - center;
         float dist_sq = dot(dc_vec, dc_vec);
@@ -236,8 +252,9 @@ LJ_HD float pdf_point_on_light(const DScene &sc, const DLight &L, f3 pos, f3 nrm
     return pdf / (2.0f * kPi * kPi * sin_el);
 }
 
+template <class Ft = FeatAll>
 LJ_HD f3 light_emission(const DScene &sc, const DLight &L, f3 view_dir, f3 light_normal) {
-    if (L.kind == 0) {  // diffuse_area_light.inl:15-20
+    if (!Ft::envmap || L.kind == 0) {  // diffuse_area_light.inl:15-20
         if (dot(light_normal, view_dir) <= 0.0f) return mk3(0, 0, 0);
         return ld3(L.intensity);
     }
@@ -246,7 +263,7 @@ LJ_HD f3 light_emission(const DScene &sc, const DLight &L, f3 view_dir, f3 light
     float dudwx = -w.z / (w.x * w.x + w.z * w.z), dudwz = w.x / (w.x * w.x + w.z * w.z);
     float dvdwy = -1.0f / sqrtf(fmaxf(1.0f - w.y * w.y, 0.0f));
     float footprint = fminf(sqrtf(dudwx * dudwx + dudwz * dudwz), dvdwy);
-    return eval_texture(sc, L.values, true, u, v, footprint) * L.scale;
+    return eval_texture<FeatAll>(sc, L.values, true, u, v, footprint) * L.scale;
 }
 
 // ------------------------------------------------------------------ BSDFs (materials/*.inl, microfacet.h)
@@ -287,8 +304,10 @@ LJ_HD f3 sample_visible_normals(f3 local_dir_in, float alpha, float r0, float r1
 }
 
 
-LJ_HD f3 tex3(const DScene &sc, const DMaterial &m, int slot, const DVertex &vx) { return eval_texture(sc, m.tex[slot], true, vx.u, vx.v, vx.uv_screen_size); }
-LJ_HD float tex1(const DScene &sc, const DMaterial &m, int slot, const DVertex &vx) { return eval_texture(sc, m.tex[slot], false, vx.u, vx.v, vx.uv_screen_size).x; }
+template <class Ft = FeatAll>
+LJ_HD f3 tex3(const DScene &sc, const DMaterial &m, int slot, const DVertex &vx) { return eval_texture<Ft>(sc, m.tex[slot], true, vx.u, vx.v, vx.uv_screen_size); }
+template <class Ft = FeatAll>
+LJ_HD float tex1(const DScene &sc, const DMaterial &m, int slot, const DVertex &vx) { return eval_texture<Ft>(sc, m.tex[slot], false, vx.u, vx.v, vx.uv_screen_size).x; }
 
 // ---- Disney family helpers (disney_metal.inl:3-50, disney_clearcoat.inl:3-16); pow(x, 5) / pow(x, 2) spelled as products
 LJ_HD float pow5(float x) { float x2 = x * x; return x2 * x2 * x; }
@@ -394,16 +413,17 @@ LJ_HD void sample_dielectric_tail(f3 dir_in, f3 h, const Frame3 &frame, float et
 
 // eval (BSDF * |cos|) and pdf together: the integrator always needs both for the same pair of directions
 // (path_tracing.h:166,187 and :251-252).
+template <class Ft = FeatAll>
 LJ_HD void bsdf_eval_pdf(const DScene &sc, const DMaterial &m, f3 dir_in, f3 dir_out, const DVertex &vx, f3 &f, float &pdf) {
     f = mk3(0, 0, 0); pdf = 0.0f;
     const bool above = !(dot(vx.gn, dir_in) < 0.0f || dot(vx.gn, dir_out) < 0.0f);
-    if (m.kind == 2) {  // roughdielectric.inl:3-88 (TransportDirection::TO_LIGHT, the only one path_tracing uses)
+    if (Ft::kind(2) && m.kind == 2) {  // roughdielectric.inl:3-88 (TransportDirection::TO_LIGHT, the only one path_tracing uses)
         bool reflect = dot(vx.gn, dir_in) * dot(vx.gn, dir_out) > 0.0f;
         Frame3 frame = frame_two_sided(vx, dir_in);
         float eta = dot(vx.gn, dir_in) > 0.0f ? m.eta : 1.0f / m.eta;
         f3 h = reflect ? normalize(dir_in + dir_out) : normalize(dir_in + dir_out * eta);
         if (dot(h, frame.n) < 0.0f) h = -h;
-        float roughness = clampf(tex1(sc, m, 2, vx), 0.01f, 1.0f);
+        float roughness = clampf(tex1<Ft>(sc, m, 2, vx), 0.01f, 1.0f);
         float h_dot_in = dot(h, dir_in);
         float F = fresnel_dielectric(h_dot_in, eta);
         float D = GTR2(dot(frame.n, h), roughness);
@@ -411,26 +431,26 @@ LJ_HD void bsdf_eval_pdf(const DScene &sc, const DMaterial &m, f3 dir_in, f3 dir
         float G = G_in * smith_masking_gtr2(to_local(frame, dir_out), roughness);
         float n_dot_in = dot(frame.n, dir_in);
         if (reflect) {
-            f = tex3(sc, m, 0, vx) * ((F * D * G) / (4.0f * fabsf(n_dot_in)));
+            f = tex3<Ft>(sc, m, 0, vx) * ((F * D * G) / (4.0f * fabsf(n_dot_in)));
             pdf = (F * D * G_in) / (4.0f * fabsf(n_dot_in));
         } else {
             float h_dot_out = dot(h, dir_out);
             float sqrt_denom = h_dot_in + eta * h_dot_out;
-            f = tex3(sc, m, 1, vx) * (((1.0f / (eta * eta)) * (1.0f - F) * D * G * eta * eta * fabsf(h_dot_out * h_dot_in)) / (fabsf(n_dot_in) * sqrt_denom * sqrt_denom));
+            f = tex3<Ft>(sc, m, 1, vx) * (((1.0f / (eta * eta)) * (1.0f - F) * D * G * eta * eta * fabsf(h_dot_out * h_dot_in)) / (fabsf(n_dot_in) * sqrt_denom * sqrt_denom));
             float dh_dout = eta * eta * h_dot_out / (sqrt_denom * sqrt_denom);
             pdf = (1.0f - F) * D * G_in * fabsf(dh_dout * h_dot_in / n_dot_in);
         }
         return;
     }
-    if (m.kind == 5) {  // disney_glass.inl
-        disney_glass_lobe(tex3(sc, m, 0, vx), tex1(sc, m, 1, vx), tex1(sc, m, 2, vx), m.eta, vx, dir_in, dir_out, f, pdf);
+    if (Ft::kind(5) && m.kind == 5) {  // disney_glass.inl
+        disney_glass_lobe(tex3<Ft>(sc, m, 0, vx), tex1<Ft>(sc, m, 1, vx), tex1<Ft>(sc, m, 2, vx), m.eta, vx, dir_in, dir_out, f, pdf);
         return;
     }
-    if (m.kind == 8) {  // disney_bsdf.inl:3-372
-        f3 base_color = tex3(sc, m, 0, vx);
-        float specular_transmission = tex1(sc, m, 1, vx), metallic = tex1(sc, m, 2, vx), subsurface = tex1(sc, m, 3, vx), specular = tex1(sc, m, 4, vx);
-        float roughness_raw = tex1(sc, m, 5, vx), specular_tint = tex1(sc, m, 6, vx), anisotropic = tex1(sc, m, 7, vx), sheen = tex1(sc, m, 8, vx);
-        float sheen_tint = tex1(sc, m, 9, vx), clearcoat = tex1(sc, m, 10, vx), clearcoat_gloss = tex1(sc, m, 11, vx);
+    if (Ft::kind(8) && m.kind == 8) {  // disney_bsdf.inl:3-372
+        f3 base_color = tex3<Ft>(sc, m, 0, vx);
+        float specular_transmission = tex1<Ft>(sc, m, 1, vx), metallic = tex1<Ft>(sc, m, 2, vx), subsurface = tex1<Ft>(sc, m, 3, vx), specular = tex1<Ft>(sc, m, 4, vx);
+        float roughness_raw = tex1<Ft>(sc, m, 5, vx), specular_tint = tex1<Ft>(sc, m, 6, vx), anisotropic = tex1<Ft>(sc, m, 7, vx), sheen = tex1<Ft>(sc, m, 8, vx);
+        float sheen_tint = tex1<Ft>(sc, m, 9, vx), clearcoat = tex1<Ft>(sc, m, 10, vx), clearcoat_gloss = tex1<Ft>(sc, m, 11, vx);
         const bool inside = dot(vx.gn, dir_in) < 0.0f;
         const bool reflect = dot(vx.gn, dir_in) * dot(vx.gn, dir_out) > 0.0f;
         f3 f_glass; float glass_pdf;
@@ -486,20 +506,20 @@ LJ_HD void bsdf_eval_pdf(const DScene &sc, const DMaterial &m, f3 dir_in, f3 dir
     Frame3 frame = vx.frame;
     if (dot(frame.n, dir_in) < 0.0f) frame = flip(frame);
     float n_dot_out = dot(frame.n, dir_out);
-    if (m.kind == 3 || m.kind == 7) {  // disney_diffuse.inl:1-58, disney_sheen.inl:3-46
+    if ((Ft::kind(3) && m.kind == 3) || (Ft::kind(7) && m.kind == 7)) {  // disney_diffuse.inl:1-58, disney_sheen.inl:3-46
         pdf = fmaxf(n_dot_out, 0.0f) * kInvPi;
-        if (m.kind == 3) f = disney_diffuse_lobe(tex3(sc, m, 0, vx), tex1(sc, m, 1, vx), tex1(sc, m, 2, vx), frame, dir_in, dir_out);
+        if (m.kind == 3) f = disney_diffuse_lobe(tex3<Ft>(sc, m, 0, vx), tex1<Ft>(sc, m, 1, vx), tex1<Ft>(sc, m, 2, vx), frame, dir_in, dir_out);
         else {
             f3 h = normalize(dir_in + dir_out);
-            float sheen_tint = tex1(sc, m, 1, vx);
-            f3 C_sheen = mk3(1, 1, 1) * (1.0f - sheen_tint) + color_tint(tex3(sc, m, 0, vx)) * sheen_tint;
+            float sheen_tint = tex1<Ft>(sc, m, 1, vx);
+            f3 C_sheen = mk3(1, 1, 1) * (1.0f - sheen_tint) + color_tint(tex3<Ft>(sc, m, 0, vx)) * sheen_tint;
             f = C_sheen * (pow5(1.0f - fabsf(dot(h, dir_out))) * fabsf(n_dot_out));
         }
         return;
     }
-    if (m.kind == 4) {  // disney_metal.inl:52-126
-        f3 base_color = tex3(sc, m, 0, vx);
-        float roughness = clampf(tex1(sc, m, 1, vx), 0.01f, 1.0f), anisotropic = tex1(sc, m, 2, vx);
+    if (Ft::kind(4) && m.kind == 4) {  // disney_metal.inl:52-126
+        f3 base_color = tex3<Ft>(sc, m, 0, vx);
+        float roughness = clampf(tex1<Ft>(sc, m, 1, vx), 0.01f, 1.0f), anisotropic = tex1<Ft>(sc, m, 2, vx);
         f3 h = normalize(dir_in + dir_out);
         f3 Fm = base_color + (mk3(1, 1, 1) - base_color) * pow5(1.0f - fabsf(dot(h, dir_out)));
         float ax, ay; aniso_alphas(roughness, anisotropic, ax, ay);
@@ -511,10 +531,10 @@ LJ_HD void bsdf_eval_pdf(const DScene &sc, const DMaterial &m, f3 dir_in, f3 dir
         f = Fm * (pdf * Gout);
         return;
     }
-    if (m.kind == 6) {  // disney_clearcoat.inl:18-66
+    if (Ft::kind(6) && m.kind == 6) {  // disney_clearcoat.inl:18-66
         f3 h = normalize(dir_in + dir_out);
         float n_dot_h = dot(frame.n, h);
-        float D = compute_Dc(tex1(sc, m, 0, vx), n_dot_h * n_dot_h);
+        float D = compute_Dc(tex1<Ft>(sc, m, 0, vx), n_dot_h * n_dot_h);
         pdf = D * fabsf(n_dot_h) / (4.0f * fabsf(dot(h, dir_out)));
         if (n_dot_h > 0.0f) {
             float G = smith_masking_gtr2(to_local(frame, dir_in), 0.5f) * smith_masking_gtr2(to_local(frame, dir_out), 0.5f);
@@ -523,18 +543,18 @@ LJ_HD void bsdf_eval_pdf(const DScene &sc, const DMaterial &m, f3 dir_in, f3 dir
         }
         return;
     }
-    if (m.kind == 0) {  // lambertian.inl:1-33
+    if (Ft::kind(0) && m.kind == 0) {  // lambertian.inl:1-33
         float c = fmaxf(n_dot_out, 0.0f);
-        f = tex3(sc, m, 0, vx) * (c * kInvPi);
+        f = tex3<Ft>(sc, m, 0, vx) * (c * kInvPi);
         pdf = c * kInvPi;
         return;
     }
-    if (m.kind == 1) {  // roughplastic.inl:3-108
+    if (Ft::kind(1) && m.kind == 1) {  // roughplastic.inl:3-108
         f3 h = normalize(dir_in + dir_out);
         float n_dot_h = dot(frame.n, h), n_dot_in = dot(frame.n, dir_in);
         if (n_dot_out <= 0.0f || n_dot_h <= 0.0f) return;
-        f3 Kd = tex3(sc, m, 0, vx), Ks = tex3(sc, m, 1, vx);
-        float roughness = clampf(tex1(sc, m, 2, vx), 0.01f, 1.0f);
+        f3 Kd = tex3<Ft>(sc, m, 0, vx), Ks = tex3<Ft>(sc, m, 1, vx);
+        float roughness = clampf(tex1<Ft>(sc, m, 2, vx), 0.01f, 1.0f);
         float F_o = fresnel_dielectric(dot(h, dir_out), m.eta);
         float D = GTR2(n_dot_h, roughness);
         float G_in = smith_masking_gtr2(to_local(frame, dir_in), roughness);
@@ -551,28 +571,29 @@ LJ_HD void bsdf_eval_pdf(const DScene &sc, const DMaterial &m, f3 dir_in, f3 dir
     }
 }
 
+template <class Ft = FeatAll>
 LJ_HD BsdfSample bsdf_sample(const DScene &sc, const DMaterial &m, f3 dir_in, const DVertex &vx, float r0, float r1, float rw) {
     BsdfSample s; s.valid = false; s.eta = 0.0f; s.roughness = 1.0f; s.dir_out = mk3(0, 0, 0);
-    if (m.kind == 2) {  // roughdielectric.inl:90-177
+    if (Ft::kind(2) && m.kind == 2) {  // roughdielectric.inl:90-177
         float eta = dot(vx.gn, dir_in) > 0.0f ? m.eta : 1.0f / m.eta;
         Frame3 fr = frame_two_sided(vx, dir_in);
-        float roughness = clampf(tex1(sc, m, 2, vx), 0.01f, 1.0f);
+        float roughness = clampf(tex1<Ft>(sc, m, 2, vx), 0.01f, 1.0f);
         f3 h = to_world(fr, sample_visible_normals(to_local(fr, dir_in), roughness * roughness, r0, r1));
         sample_dielectric_tail(dir_in, h, fr, eta, roughness, rw, s);
         return s;
     }
-    if (m.kind == 5) {  // disney_glass.inl:137-205
+    if (Ft::kind(5) && m.kind == 5) {  // disney_glass.inl:137-205
         Frame3 fr = frame_two_sided(vx, dir_in);
         float eta = dot(vx.gn, dir_in) > 0.0f ? m.eta : 1.0f / m.eta;
-        float roughness = clampf(tex1(sc, m, 1, vx), 0.01f, 1.0f);
-        float ax, ay; aniso_alphas(roughness, tex1(sc, m, 2, vx), ax, ay);
+        float roughness = clampf(tex1<Ft>(sc, m, 1, vx), 0.01f, 1.0f);
+        float ax, ay; aniso_alphas(roughness, tex1<Ft>(sc, m, 2, vx), ax, ay);
         f3 h = to_world(fr, sample_visible_normals_aniso(to_local(fr, dir_in), ax, ay, r0, r1));
         sample_dielectric_tail(dir_in, h, fr, eta, roughness, rw, s);
         return s;
     }
-    if (m.kind == 8) {  // disney_bsdf.inl:374-572
-        float specular_transmission = tex1(sc, m, 1, vx), metallic = tex1(sc, m, 2, vx), anisotropic = tex1(sc, m, 7, vx);
-        float clearcoat = tex1(sc, m, 10, vx);
+    if (Ft::kind(8) && m.kind == 8) {  // disney_bsdf.inl:374-572
+        float specular_transmission = tex1<Ft>(sc, m, 1, vx), metallic = tex1<Ft>(sc, m, 2, vx), anisotropic = tex1<Ft>(sc, m, 7, vx);
+        float clearcoat = tex1<Ft>(sc, m, 10, vx);
         float eta = dot(vx.gn, dir_in) > 0.0f ? m.eta : 1.0f / m.eta;
         float diffuse_weight = (1.0f - metallic) * (1.0f - specular_transmission);
         float metal_weight = 1.0f - specular_transmission * (1.0f - metallic);
@@ -589,19 +610,19 @@ LJ_HD BsdfSample bsdf_sample(const DScene &sc, const DMaterial &m, f3 dir_in, co
         if (dot(fr.n, dir_in) < 0.0f) fr = flip(fr);
         if (rw < diffuse_weight) { s.dir_out = to_world(fr, sample_cos_hemisphere(r0, r1)); s.valid = true; }
         else if (rw < diffuse_weight + metal_weight) {
-            float roughness = clampf(tex1(sc, m, 5, vx), 0.01f, 1.0f);
+            float roughness = clampf(tex1<Ft>(sc, m, 5, vx), 0.01f, 1.0f);
             float ax, ay; aniso_alphas(roughness, anisotropic, ax, ay);
             f3 h = to_world(fr, sample_visible_normals_aniso(to_local(fr, dir_in), ax, ay, r0, r1));
             s.dir_out = normalize(-dir_in + h * (2.0f * dot(dir_in, h))); s.roughness = roughness; s.valid = true;
         } else if (rw < diffuse_weight + metal_weight + glass_weight) {
             Frame3 f2 = frame_two_sided(vx, dir_in);
-            float roughness = clampf(tex1(sc, m, 5, vx), 0.01f, 1.0f);
+            float roughness = clampf(tex1<Ft>(sc, m, 5, vx), 0.01f, 1.0f);
             float ax, ay; aniso_alphas(roughness, anisotropic, ax, ay);
             f3 h = to_world(f2, sample_visible_normals_aniso(to_local(f2, dir_in), ax, ay, r0, r1));
             float rand_new = (rw - (diffuse_weight + metal_weight)) / glass_weight;
             sample_dielectric_tail(dir_in, h, f2, eta, roughness, rand_new, s);
         } else {
-            f3 h = to_world(fr, sample_clearcoat_half(tex1(sc, m, 11, vx), r0, r1));
+            f3 h = to_world(fr, sample_clearcoat_half(tex1<Ft>(sc, m, 11, vx), r0, r1));
             s.dir_out = normalize(-dir_in + h * (2.0f * dot(dir_in, h))); s.valid = true;
         }
         return s;
@@ -609,33 +630,33 @@ LJ_HD BsdfSample bsdf_sample(const DScene &sc, const DMaterial &m, f3 dir_in, co
     if (dot(vx.gn, dir_in) < 0.0f) return s;  // one-sided materials (lambertian.inl:37-40 and the like)
     Frame3 frame = vx.frame;
     if (dot(frame.n, dir_in) < 0.0f) frame = flip(frame);
-    if (m.kind == 3 || m.kind == 7) {  // disney_diffuse.inl:60-76, disney_sheen.inl:48-62
+    if ((Ft::kind(3) && m.kind == 3) || (Ft::kind(7) && m.kind == 7)) {  // disney_diffuse.inl:60-76, disney_sheen.inl:48-62
         s.dir_out = to_world(frame, sample_cos_hemisphere(r0, r1)); s.valid = true;
         return s;
     }
-    if (m.kind == 4) {  // disney_metal.inl:128-162
-        float roughness = clampf(tex1(sc, m, 1, vx), 0.01f, 1.0f);
-        float ax, ay; aniso_alphas(roughness, tex1(sc, m, 2, vx), ax, ay);
+    if (Ft::kind(4) && m.kind == 4) {  // disney_metal.inl:128-162
+        float roughness = clampf(tex1<Ft>(sc, m, 1, vx), 0.01f, 1.0f);
+        float ax, ay; aniso_alphas(roughness, tex1<Ft>(sc, m, 2, vx), ax, ay);
         f3 h = to_world(frame, sample_visible_normals_aniso(to_local(frame, dir_in), ax, ay, r0, r1));
         s.dir_out = normalize(-dir_in + h * (2.0f * dot(dir_in, h))); s.roughness = roughness; s.valid = true;
         return s;
     }
-    if (m.kind == 6) {  // disney_clearcoat.inl:68-106
-        f3 h = to_world(frame, sample_clearcoat_half(tex1(sc, m, 0, vx), r0, r1));
+    if (Ft::kind(6) && m.kind == 6) {  // disney_clearcoat.inl:68-106
+        f3 h = to_world(frame, sample_clearcoat_half(tex1<Ft>(sc, m, 0, vx), r0, r1));
         s.dir_out = normalize(-dir_in + h * (2.0f * dot(dir_in, h))); s.valid = true;
         return s;
     }
-    if (m.kind == 0) {  // lambertian.inl:35-50
+    if (Ft::kind(0) && m.kind == 0) {  // lambertian.inl:35-50
         s.dir_out = to_world(frame, sample_cos_hemisphere(r0, r1)); s.valid = true;
         return s;
     }
-    if (m.kind == 1) {  // roughplastic.inl:110-161
-        f3 Ks = tex3(sc, m, 1, vx), Kd = tex3(sc, m, 0, vx);
+    if (Ft::kind(1) && m.kind == 1) {  // roughplastic.inl:110-161
+        f3 Ks = tex3<Ft>(sc, m, 1, vx), Kd = tex3<Ft>(sc, m, 0, vx);
         float lS = luminance(Ks), lR = luminance(Kd);
         if (lS + lR <= 0.0f) return s;
         float spec_prob = lS / (lS + lR);
         if (rw < spec_prob) {
-            float roughness = clampf(tex1(sc, m, 2, vx), 0.01f, 1.0f);
+            float roughness = clampf(tex1<Ft>(sc, m, 2, vx), 0.01f, 1.0f);
             f3 hm = to_world(frame, sample_visible_normals(to_local(frame, dir_in), roughness * roughness, r0, r1));
             s.dir_out = normalize(-dir_in + hm * (2.0f * dot(dir_in, hm)));
             s.roughness = roughness;
@@ -687,6 +708,7 @@ LJ_HD void generate_path(const DScene &sc, const DPass &pass, uint32_t sample_id
 // next (path_tracing.h:58-61 for camera rays; :239-322 tail of iteration k, then :94-237 head of iteration k+1).
 // Returns true if the path continues (ps holds the next extension + shadow rays), false if it is finished
 // (ps.rad is the value of path_tracing() for this sample).
+template <class Ft = FeatAll>
 LJ_HD bool shade_path(const DScene &sc, const DPass &pass, PathState &ps, ShadeCounters &cnt) {
     const uint64_t inc = pcg32_inc((uint64_t)pass.pixel_list[ps.sample / pass.spp] * pass.spp + (ps.sample % pass.spp));
     // pending next-event estimation of the previous vertex (path_tracing.h:207)
@@ -696,12 +718,12 @@ LJ_HD bool shade_path(const DScene &sc, const DPass &pass, PathState &ps, ShadeC
     const int gprim = (ps.hcode & 0x3fffffff) - 1;
     const uint32_t nv_prev = ps.flags & 0xffffu;
     if (gprim < 0) {  // miss: environment map (path_tracing.h:17-27 camera rays, :284-302 bounces)
-        if (sc.envmap_light_id >= 0) {
+        if (Ft::envmap && sc.envmap_light_id >= 0) {
             const DLight &E = sc.lights[sc.envmap_light_id];
-            f3 L = light_emission(sc, E, -ps.dir, mk3(0, 0, 0));
+            f3 L = light_emission<Ft>(sc, E, -ps.dir, mk3(0, 0, 0));
             if (primary) ps.rad = ps.rad + L;
             else {
-                float p1 = E.pmf * pdf_point_on_light(sc, E, mk3(0, 0, 0), -ps.dir, ps.org);
+                float p1 = E.pmf * pdf_point_on_light<Ft>(sc, E, mk3(0, 0, 0), -ps.dir, ps.org);
                 float p2 = ps.p2;  // G = 1
                 float w2 = (p2 * p2) / (p1 * p1 + p2 * p2);
                 ps.rad = ps.rad + ps.W * L * w2;
@@ -712,13 +734,13 @@ LJ_HD bool shade_path(const DScene &sc, const DPass &pass, PathState &ps, ShadeC
     DVertex vx = build_vertex(sc, ps.org, ps.dir, ps.ht, ps.hu, ps.hv, gprim, primary ? ps.spread : 0.0f);
     if (vx.light_id >= 0) {  // hit an emitter (path_tracing.h:58-61, :268-283)
         const DLight &EL = sc.lights[vx.light_id];
-        f3 L = light_emission(sc, EL, -ps.dir, vx.gn);
+        f3 L = light_emission<Ft>(sc, EL, -ps.dir, vx.gn);
         if (primary) ps.rad = ps.rad + L;
         else {
             f3 dv = vx.position - ps.org;
             float G = fabsf(dot(ps.dir, vx.gn)) / dot(dv, dv);
             float p2 = ps.p2 * G;
-            float p1 = EL.pmf * pdf_point_on_light(sc, EL, vx.position, vx.gn, ps.org);
+            float p1 = EL.pmf * pdf_point_on_light<Ft>(sc, EL, vx.position, vx.gn, ps.org);
             float w2 = (p2 * p2) / (p1 * p1 + p2 * p2);
             ps.rad = ps.rad + ps.W * L * w2;
         }
@@ -737,22 +759,22 @@ LJ_HD bool shade_path(const DScene &sc, const DPass &pass, PathState &ps, ShadeC
     float light_w = pcg32_real(ps.rng, inc), shape_w = pcg32_real(ps.rng, inc);
     int light_id = sample_cdf(sc.light_cdf, sc.n_lights, light_w);
     const DLight &Lt = sc.lights[light_id];
-    LightSample pl = sample_point_on_light(sc, Lt, vx.position, lu0, lu1, shape_w);
+    LightSample pl = sample_point_on_light<Ft>(sc, Lt, vx.position, lu0, lu1, shape_w);
     ps.nee = mk3(0, 0, 0); ps.sdir = mk3(0, 0, 0); ps.stfar = 0.0f;
     {
         float G; f3 dir_light; float tfar;
-        if (Lt.kind == 0) {
+        if (!Ft::envmap || Lt.kind == 0) {
             f3 dl = pl.position - vx.position;
             float d2 = dot(dl, dl), d = sqrtf(d2);
             dir_light = normalize(dl);
             tfar = (1.0f - sc.eps) * d;
             G = fmaxf(-dot(dir_light, pl.normal), 0.0f) / d2;
         } else { dir_light = -pl.normal; tfar = INFINITY; G = 1.0f; }
-        float p1 = Lt.pmf * pdf_point_on_light(sc, Lt, pl.position, pl.normal, vx.position);
+        float p1 = Lt.pmf * pdf_point_on_light<Ft>(sc, Lt, pl.position, pl.normal, vx.position);
         if (G > 0.0f && p1 > 0.0f) {
             f3 f; float p2;
-            bsdf_eval_pdf(sc, mat, dir_view, dir_light, vx, f, p2);
-            f3 Le = light_emission(sc, Lt, -dir_light, pl.normal);
+            bsdf_eval_pdf<Ft>(sc, mat, dir_view, dir_light, vx, f, p2);
+            f3 Le = light_emission<Ft>(sc, Lt, -dir_light, pl.normal);
             f3 C1 = f * Le * (G / p1);
             p2 *= G;
             float w1 = (p1 * p1) / (p1 * p1 + p2 * p2);
@@ -765,14 +787,14 @@ LJ_HD bool shade_path(const DScene &sc, const DPass &pass, PathState &ps, ShadeC
     }
     // ---- BSDF sampling (path_tracing.h:210-237)
     float b0 = pcg32_real(ps.rng, inc), b1 = pcg32_real(ps.rng, inc), bw = pcg32_real(ps.rng, inc);
-    BsdfSample bs = bsdf_sample(sc, mat, dir_view, vx, b0, b1, bw);
+    BsdfSample bs = bsdf_sample<Ft>(sc, mat, dir_view, vx, b0, b1, bw);
     ps.org = vx.position;
     ps.flags = nv;
     if (!bs.valid) { ps.flags |= PF_NO_EXT; ps.dir = mk3(0, 0, 1); return ps.stfar > 0.0f; }
     if (bs.eta == 0.0f) ps.spread = fmaxf(ps.spread * (1.0f - bs.roughness) + 0.2f * bs.roughness, 0.0f);  // ray.h:45-51, radius == 0
     else { ps.spread = fmaxf((ps.spread / bs.eta) * (1.0f - bs.roughness) + 0.2f * bs.roughness, 0.0f); ps.eta_scale /= (bs.eta * bs.eta); }
     f3 f; float p2;
-    bsdf_eval_pdf(sc, mat, dir_view, bs.dir_out, vx, f, p2);
+    bsdf_eval_pdf<Ft>(sc, mat, dir_view, bs.dir_out, vx, f, p2);
     if (!(p2 > 0.0f)) { ps.flags |= PF_NO_EXT; ps.dir = mk3(0, 0, 1); return ps.stfar > 0.0f; }  // path_tracing.h:253-256
     ps.dir = bs.dir_out;
     ps.W = thr * f / p2; ps.p2 = p2;

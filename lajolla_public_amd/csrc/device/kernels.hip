@@ -326,7 +326,18 @@ __device__ __forceinline__ void lds_copy16(void *dst, const void *src, uint32_t 
     for (uint32_t i = threadIdx.x; i < bytes / 16; i += kBlock) d4[i] = s4[i];
 }
 
-__global__ void __launch_bounds__(kBlock, 4) k_shade(DScene sc, DPass pass, DQueue q, DBlockState *blocks, uint32_t seg, ShadeStage stg, uint32_t *work, uint32_t *chunk_list, uint32_t parity) {
+// Feature sets the shade kernel is compiled for, smallest first.  kinds: bit k = Material alternative k.
+using FeatLambert = ShadeFeat<0x001u, false, false, false>;      // constant-colour diffuse surfaces, mesh lights (cbox)
+using FeatLambertTex = ShadeFeat<0x001u, true, false, true>;     // + image / checker textures, sphere lights (sponza)
+using FeatClassic = ShadeFeat<0x007u, true, true, true>;         // diffuse, roughplastic, roughdielectric + everything else
+#ifndef LJ_LAMBERT_OCC
+#define LJ_LAMBERT_OCC 4
+#endif
+template <class Ft> struct ShadeOccupancy { static constexpr int waves = 4; };
+template <> struct ShadeOccupancy<FeatLambert> { static constexpr int waves = LJ_LAMBERT_OCC; };
+
+template <class Ft>
+__global__ void __launch_bounds__(kBlock, ShadeOccupancy<Ft>::waves) k_shade(DScene sc, DPass pass, DQueue q, DBlockState *blocks, uint32_t seg, ShadeStage stg, uint32_t *work, uint32_t *chunk_list, uint32_t parity) {
     __shared__ uint32_t s_list_base;
     if (blockIdx.x == 0 && threadIdx.x == 0) work[0] = 0u;   // the extend launch that follows draws its chunks from it
     __shared__ uint32_t s_wcnt[2][kBlock / 64];
@@ -354,7 +365,7 @@ __global__ void __launch_bounds__(kBlock, 4) k_shade(DScene sc, DPass pass, DQue
         PathState ps;
         if (j < count) {
             q_load_for_shade(q, base + j, ps);
-            alive = shade_path(sc, pass, ps, cnt);
+            alive = shade_path<Ft>(sc, pass, ps, cnt);
             if (!alive) {
                 float *o = pass.sample_rgb + 3ull * ps.sample;
                 o[0] = ps.rad.x; o[1] = ps.rad.y; o[2] = ps.rad.z;
@@ -471,15 +482,16 @@ ExtendConfig extend_config(int n_nodes, int n_prims, int bvh_depth) {
 int max_stack_depth() { return 40; }  // inner levels; the builder's own cap is 38
 
 // LDS staging plan of the shade kernel; sizes are rounded up to 16 bytes (the device buffers are padded accordingly).
-struct ShadeConfig { uint32_t prims_bytes, materials_bytes, lights_bytes, light_cdf_bytes, light_tris_bytes, light_tri_cdf_bytes, stage_prims; size_t smem; };
+struct ShadeConfig { uint32_t prims_bytes, materials_bytes, lights_bytes, light_cdf_bytes, light_tris_bytes, light_tri_cdf_bytes, stage_prims; int variant; size_t smem; };
 ShadeConfig shade_config(size_t n_prims, size_t n_materials, size_t n_lights, size_t n_light_tris, size_t n_light_tri_cdf) {
     auto r16 = [](size_t b) { return (uint32_t)((b + 15) & ~(size_t)15); };
     ShadeConfig c{};
+    c.variant = 3;
     c.materials_bytes = r16(n_materials * sizeof(DMaterial)); c.lights_bytes = r16(n_lights * sizeof(DLight));
     c.light_cdf_bytes = r16((n_lights + 1) * 4); c.light_tris_bytes = r16(n_light_tris * sizeof(DLightTri)); c.light_tri_cdf_bytes = r16(n_light_tri_cdf * 4);
     size_t small = (size_t)c.materials_bytes + c.lights_bytes + c.light_cdf_bytes + c.light_tris_bytes + c.light_tri_cdf_bytes;
     if (small > 24 * 1024) {  // too many materials / emissive triangles: leave everything in global memory
-        c = ShadeConfig{}; c.smem = 0; return c;
+        c = ShadeConfig{}; c.variant = 3; c.smem = 0; return c;
     }
     c.prims_bytes = r16(n_prims * sizeof(DPrimShade));
     c.stage_prims = (small + c.prims_bytes <= 32 * 1024) ? 1u : 0u;
@@ -495,11 +507,26 @@ void launch_extend(const DScene &sc, const DQueue &q, const DBlockState *blocks,
     if (stats) { if (cfg.resident) launch(k_extend<true, true>); else launch(k_extend<true, false>); }
     else { if (cfg.resident) launch(k_extend<false, true>); else launch(k_extend<false, false>); }
 }
+// shade_variant() returns the first (smallest) feature set that covers a scene
+int shade_variant(uint32_t kinds, bool textured, bool envmap, bool sphere_lights) {
+    auto covers = [&](uint32_t k, bool t, bool e, bool s) { return (kinds & ~k) == 0u && (t || !textured) && (e || !envmap) && (s || !sphere_lights); };
+    if (covers(FeatLambert::kinds, FeatLambert::textured, FeatLambert::envmap, FeatLambert::sphere_lights)) return 0;
+    if (covers(FeatLambertTex::kinds, FeatLambertTex::textured, FeatLambertTex::envmap, FeatLambertTex::sphere_lights)) return 1;
+    if (covers(FeatClassic::kinds, FeatClassic::textured, FeatClassic::envmap, FeatClassic::sphere_lights)) return 2;
+    return 3;
+}
+
 void launch_shade(const DScene &sc, const DPass &pass, const DQueue &q, DBlockState *blocks, uint32_t n_blocks, uint32_t seg, const ShadeConfig &cfg, uint32_t *work, uint32_t *chunk_list, uint32_t parity, hipStream_t s) {
     ShadeStage st;
     st.prims_bytes = cfg.prims_bytes; st.materials_bytes = cfg.materials_bytes; st.lights_bytes = cfg.lights_bytes; st.light_cdf_bytes = cfg.light_cdf_bytes;
     st.light_tris_bytes = cfg.light_tris_bytes; st.light_tri_cdf_bytes = cfg.light_tri_cdf_bytes; st.stage_prims = cfg.stage_prims;
-    hipLaunchKernelGGL(k_shade, dim3(n_blocks), dim3(kBlock), cfg.smem, s, sc, pass, q, blocks, seg, st, work, chunk_list, parity);
+    auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(n_blocks), dim3(kBlock), cfg.smem, s, sc, pass, q, blocks, seg, st, work, chunk_list, parity); };
+    switch (cfg.variant) {
+        case 0: launch(k_shade<FeatLambert>); break;
+        case 1: launch(k_shade<FeatLambertTex>); break;
+        case 2: launch(k_shade<FeatClassic>); break;
+        default: launch(k_shade<FeatAll>); break;
+    }
 }
 void launch_resolve(const DPass &pass, uint32_t n_pixels, float *rgb, hipStream_t s) {
     const uint32_t waves_per_block = kBlock / 64;
