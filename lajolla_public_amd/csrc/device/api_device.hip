@@ -20,7 +20,7 @@ int shade_variant(uint32_t kinds, bool textured, bool envmap, bool sphere_lights
 ExtendConfig extend_config(int n_nodes, int n_prims, int bvh_depth);
 int max_stack_depth();
 void launch_extend(const DScene &sc, const DQueue &q, const DBlockState *blocks, uint32_t grid, uint32_t seg, uint32_t *work, const uint32_t *chunk_list, uint32_t parity, const ExtendConfig &cfg, int *spill, unsigned long long *stats, hipStream_t s);
-void launch_shade(const DScene &sc, const DPass &pass, const DQueue &q, DBlockState *blocks, uint32_t n_blocks, uint32_t seg, const ShadeConfig &cfg, uint32_t *work, uint32_t *chunk_list, uint32_t parity, hipStream_t s);
+void launch_shade(const DScene &sc, const DPass &pass, const DQueue &q, DBlockState *blocks, uint32_t n_blocks, uint32_t seg, const ShadeConfig &cfg, uint32_t *work, uint32_t *chunk_list, uint32_t parity, uint32_t extend_waves, hipStream_t s);
 void launch_resolve(const DPass &pass, uint32_t n_pixels, float *rgb, hipStream_t s);
 void launch_trace_rays(const DScene &sc, const void *rays, long long n, void *hits, unsigned char *occ, const ExtendConfig &cfg, int *spill, int grid, hipStream_t s);
 }
@@ -209,16 +209,16 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
         // step 0 is a shade over empty segments: it only generates camera rays
         HIP_CHECK(hipMemsetAsync(work, 0, 64, stream));
         parity = 0;
-        ljd::launch_shade(ds, pass, q, dblocks, n_blocks, seg, sc->scfg, work, chunk_lists[parity], parity, stream);
+        ljd::launch_shade(ds, pass, q, dblocks, n_blocks, seg, sc->scfg, work, chunk_lists[parity], parity, ext_grid * 4u, stream);
         bool done = false;
+        int batch = 8;  // steps per host round trip; all per-step state lives on the device
         for (int guard = 0; guard < (1 << 20) && !done; guard++) {
-            const int batch = 8;  // steps per host round trip; all per-step state lives on the device
             for (int b = 0; b < batch; b++) {
                 if (timing) HIP_CHECK(hipEventRecord(ctx->ev_k0, stream));
                 ljd::launch_extend(ds, q, dblocks, ext_grid, seg, work, chunk_lists[parity], parity, sc->ecfg, spill, xstats, stream);
                 if (timing) HIP_CHECK(hipEventRecord(ctx->ev_k1, stream));
                 parity ^= 1u;
-                ljd::launch_shade(ds, pass, q, dblocks, n_blocks, seg, sc->scfg, work, chunk_lists[parity], parity, stream);
+                ljd::launch_shade(ds, pass, q, dblocks, n_blocks, seg, sc->scfg, work, chunk_lists[parity], parity, ext_grid * 4u, stream);
                 if (timing) {
                     HIP_CHECK(hipEventRecord(ctx->ev_end, stream));
                     HIP_CHECK(hipEventSynchronize(ctx->ev_end));
@@ -234,6 +234,8 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
             uint64_t alive = 0;
             for (uint32_t b = 0; b < n_blocks; b++) alive += ctx->blocks_host[b].count;
             done = alive == 0;
+            // the long tail (a few deep paths left): launches are nearly empty, so look less often
+            batch = alive * 64ull < (uint64_t)n_slots ? 16 : 8;
         }
         uint64_t samples_done = 0, path_steps = 0;
         for (uint32_t b = 0; b < n_blocks; b++) {

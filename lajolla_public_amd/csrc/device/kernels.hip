@@ -214,14 +214,18 @@ __global__ void __launch_bounds__(kBlock, 4) k_extend(DScene sc, DQueue q, const
     unsigned long long st_outer = 0, st_busy = 0, st_nodes = 0, st_node_lanes = 0, st_leaf = 0, st_leaf_lanes = 0, st_refill = 0, st_rays = 0;
     const TreeView tv = stage_tree(sc, stack, lds_nodes, lds_prims, spill, gridDim.x * kBlock, blockIdx.x * kBlock + threadIdx.x);
     // Persistent waves: the shade launch before this one listed the chunks (kChunk queue slots inside one of its
-    // segments) that hold live paths; every wave draws its next chunk from one grid-wide counter, so the launch stays
-    // balanced whatever the rays cost.  work[0] = draw counter, work[1 + parity] = length of this step's list.
+    // segments) that hold live paths.  Wave w starts with list entry w; if the list is longer than the grid has
+    // waves, the rest is drawn from one grid-wide counter (which the shade launch preset to the number of waves), so
+    // the launch stays balanced whatever the rays cost.  A launch over a short list issues no atomic at all — a
+    // single address takes only ~90 atomics per microsecond, which would otherwise put a ~50 us floor under every
+    // launch of the render's long tail.  work[0] = draw counter, work[1 + parity] = length of this step's list.
     const uint32_t n_chunks = work[1 + parity];
     if (blockIdx.x == 0 && threadIdx.x == 0) work[1 + (parity ^ 1u)] = 0u;   // the next shade launch appends to the other list
     uint32_t *chunk_counter = work;
     const bool leader = (threadIdx.x & 63u) == 0u;
-    uint32_t pre = 0;                       // prefetched list position (valid in the wave's first lane)
-    if (leader) pre = atomicAdd(chunk_counter, 1u);
+    const uint32_t n_waves = gridDim.x * (kBlock / 64u);
+    const bool draw = n_chunks > n_waves;   // uniform over the grid
+    uint32_t pre = blockIdx.x * (kBlock / 64u) + (threadIdx.x >> 6);   // next list position (valid in the wave's first lane)
     uint32_t next = 0, end = 0;             // live slots of the open chunk (wave-uniform)
     bool exhausted = false;
     // per-lane state: phase 0 = shadow ray (any hit), phase 1 = extension ray (closest hit)
@@ -236,7 +240,8 @@ __global__ void __launch_bounds__(kBlock, 4) k_extend(DScene sc, DQueue q, const
                 const uint32_t slot0 = chunk_list[c] * kChunk, b = slot0 / seg, off = slot0 - b * seg, cnt = blocks[b].count;
                 const uint32_t live = cnt > off ? (cnt - off < kChunk ? cnt - off : kChunk) : 0u;
                 next = slot0; end = slot0 + live;
-                if (leader) pre = atomicAdd(chunk_counter, 1u);
+                if (draw) { if (leader) pre = atomicAdd(chunk_counter, 1u); }
+                else pre = 0xffffffffu;
                 if (live == 0u) continue;
             }
         }
@@ -337,9 +342,9 @@ template <class Ft> struct ShadeOccupancy { static constexpr int waves = 4; };
 template <> struct ShadeOccupancy<FeatLambert> { static constexpr int waves = LJ_LAMBERT_OCC; };
 
 template <class Ft>
-__global__ void __launch_bounds__(kBlock, ShadeOccupancy<Ft>::waves) k_shade(DScene sc, DPass pass, DQueue q, DBlockState *blocks, uint32_t seg, ShadeStage stg, uint32_t *work, uint32_t *chunk_list, uint32_t parity) {
+__global__ void __launch_bounds__(kBlock, ShadeOccupancy<Ft>::waves) k_shade(DScene sc, DPass pass, DQueue q, DBlockState *blocks, uint32_t seg, ShadeStage stg, uint32_t *work, uint32_t *chunk_list, uint32_t parity, uint32_t extend_waves) {
     __shared__ uint32_t s_list_base;
-    if (blockIdx.x == 0 && threadIdx.x == 0) work[0] = 0u;   // the extend launch that follows draws its chunks from it
+    if (blockIdx.x == 0 && threadIdx.x == 0) work[0] = extend_waves;   // the extend launch that follows draws list entries beyond its own waves from it
     __shared__ uint32_t s_wcnt[2][kBlock / 64];
     __shared__ unsigned long long s_cnt[5];
     {
@@ -516,11 +521,11 @@ int shade_variant(uint32_t kinds, bool textured, bool envmap, bool sphere_lights
     return 3;
 }
 
-void launch_shade(const DScene &sc, const DPass &pass, const DQueue &q, DBlockState *blocks, uint32_t n_blocks, uint32_t seg, const ShadeConfig &cfg, uint32_t *work, uint32_t *chunk_list, uint32_t parity, hipStream_t s) {
+void launch_shade(const DScene &sc, const DPass &pass, const DQueue &q, DBlockState *blocks, uint32_t n_blocks, uint32_t seg, const ShadeConfig &cfg, uint32_t *work, uint32_t *chunk_list, uint32_t parity, uint32_t extend_waves, hipStream_t s) {
     ShadeStage st;
     st.prims_bytes = cfg.prims_bytes; st.materials_bytes = cfg.materials_bytes; st.lights_bytes = cfg.lights_bytes; st.light_cdf_bytes = cfg.light_cdf_bytes;
     st.light_tris_bytes = cfg.light_tris_bytes; st.light_tri_cdf_bytes = cfg.light_tri_cdf_bytes; st.stage_prims = cfg.stage_prims;
-    auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(n_blocks), dim3(kBlock), cfg.smem, s, sc, pass, q, blocks, seg, st, work, chunk_list, parity); };
+    auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(n_blocks), dim3(kBlock), cfg.smem, s, sc, pass, q, blocks, seg, st, work, chunk_list, parity, extend_waves); };
     switch (cfg.variant) {
         case 0: launch(k_shade<FeatLambert>); break;
         case 1: launch(k_shade<FeatLambertTex>); break;
