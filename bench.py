@@ -22,6 +22,29 @@ sys.path.insert(0, ROOT)
 PEAK_HBM_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6.3 TB/s is what a copy kernel achieves
 
 
+def host_cores():
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota when there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def profiled_traffic(kernel, launches):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same workload
+    (profiles/r01_hbm_traffic.json, written by tools/prof_bench.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md)."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
+        k = t["kernels"][kernel]
+        return int((k["fetch_bytes"] + k["write_bytes"]) / max(k["launches"], 1)), t["source"]
+    except (OSError, KeyError, ValueError):
+        return None, None
+
+
 def cpu_baseline(scene_xml, seconds_budget=20.0):
     """The CPU restatement of the reference's parallel.cpp tile path (oracle/, `port`), all host cores, on a bounded
     sample of the same workload: cbox 512x512 at a reduced spp chosen to take roughly `seconds_budget`."""
@@ -30,7 +53,7 @@ def cpu_baseline(scene_xml, seconds_budget=20.0):
     from helpers import Oracle
     hs = lj.parse_scene(scene_xml)
     o = Oracle(hs)
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     rc, _, _, st = o.render(spp=1, rng_mode=1, threads=cores)  # probe
     rate = st.samples / max(st.seconds, 1e-9)
     spp = int(max(1, min(256, round(seconds_budget * rate / (hs.width * hs.height)))))
@@ -111,8 +134,10 @@ def main():
     kd = kernels[dom]
     avg_us = kd["ms"] * 1e3 / max(kd["launches"], 1)
     achieved = (kd["bytes"] / max(kd["launches"], 1)) / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
+    is_default = os.path.basename(args.scene) == "cbox.xml" and spp == 256 and world == 1
+    traffic, traffic_source = profiled_traffic(dom, kd["launches"]) if is_default else (None, None)
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                "frac": round(achieved / PEAK_HBM_GBS, 5), "traffic": None,
+                "frac": round(achieved / PEAK_HBM_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
                 "avg_launch_us": round(avg_us, 2), "algorithmic_bytes_per_launch": int(kd["bytes"] / max(kd["launches"], 1)),
                 "all_kernels": {k: {"total_ms": round(v["ms"], 3), "launches": int(v["launches"]),
                                     "GBps": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 2)} for k, v in kernels.items()},
