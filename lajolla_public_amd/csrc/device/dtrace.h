@@ -2,7 +2,7 @@
 // (intersection.cpp:32,83) and the sphere user-geometry callbacks (sphere.inl:40-141).
 //
 // The primitive tests are the SAME arithmetic, operation for operation, as oracle/lj_oracle.cpp's tri_test /
-// sphere_test, compiled with floating-point contraction off, so a hit record (t, u, v, primitive) is bit-identical
+// sphere_test, compiled with floating-point contraction off (the fused multiply-adds are the ones written out), so a hit record (t, u, v, primitive) is bit-identical
 // between the two for the same float ray.  The closest hit is the minimum of (t, global primitive id), which makes
 // the result independent of BVH topology and traversal order.
 #pragma once
@@ -16,6 +16,11 @@ namespace ljd {
 
 struct RayF { float ox, oy, oz, dx, dy, dz, tnear, tfar; };
 
+// a*b - c*d and x*dx + y*dy + z*dz with explicit fused multiply-adds (IEEE fma is exactly specified, so the CPU oracle and
+// the GPU agree bit for bit).  Negating (a, c) negates the first exactly and negating (x, y, z) the second, which is what
+// keeps the edge tests of two triangles sharing an edge exact mirror images.
+#define LJ_TRI_CROSS(a, b, c, d) __builtin_fmaf((a), (b), -((c) * (d)))
+#define LJ_TRI_DOT(x, y, z, dx, dy, dz) __builtin_fmaf((z), (dz), __builtin_fmaf((y), (dy), (x) * (dx)))
 // Plücker-coordinate edge tests on origin-relative vertices; see oracle/lj_oracle.cpp tri_test for the rationale.
 LJ_HD bool tri_test(const RayF &r, float tfar, const float *p0, const float *p1, const float *p2, float &t_out, float &u_out, float &v_out) {
     float ax = p0[0] - r.ox, ay = p0[1] - r.oy, az = p0[2] - r.oz;
@@ -27,20 +32,21 @@ LJ_HD bool tri_test(const RayF &r, float tfar, const float *p0, const float *p1,
     float s0x = cx + ax, s0y = cy + ay, s0z = cz + az;
     float s1x = ax + bx, s1y = ay + by, s1z = az + bz;
     float s2x = bx + cx, s2y = by + cy, s2z = bz + cz;
-    float U = (e0y * s0z - e0z * s0y) * r.dx + (e0z * s0x - e0x * s0z) * r.dy + (e0x * s0y - e0y * s0x) * r.dz;
-    float V = (e1y * s1z - e1z * s1y) * r.dx + (e1z * s1x - e1x * s1z) * r.dy + (e1x * s1y - e1y * s1x) * r.dz;
-    float W = (e2y * s2z - e2z * s2y) * r.dx + (e2z * s2x - e2x * s2z) * r.dy + (e2x * s2y - e2y * s2x) * r.dz;
+    float U = LJ_TRI_DOT(LJ_TRI_CROSS(e0y, s0z, e0z, s0y), LJ_TRI_CROSS(e0z, s0x, e0x, s0z), LJ_TRI_CROSS(e0x, s0y, e0y, s0x), r.dx, r.dy, r.dz);
+    float V = LJ_TRI_DOT(LJ_TRI_CROSS(e1y, s1z, e1z, s1y), LJ_TRI_CROSS(e1z, s1x, e1x, s1z), LJ_TRI_CROSS(e1x, s1y, e1y, s1x), r.dx, r.dy, r.dz);
+    float W = LJ_TRI_DOT(LJ_TRI_CROSS(e2y, s2z, e2z, s2y), LJ_TRI_CROSS(e2z, s2x, e2x, s2z), LJ_TRI_CROSS(e2x, s2y, e2y, s2x), r.dx, r.dy, r.dz);
     float mn = fminf(fminf(U, V), W), mx = fmaxf(fmaxf(U, V), W);
     if (!(mn >= 0.0f || mx <= 0.0f)) return false;
     float S = (U + V) + W;
     if (S == 0.0f) return false;
-    float nx = e1y * e0z - e1z * e0y, ny = e1z * e0x - e1x * e0z, nz = e1x * e0y - e1y * e0x;
-    float den = (nx * r.dx + ny * r.dy) + nz * r.dz;
+    float nx = LJ_TRI_CROSS(e1y, e0z, e1z, e0y), ny = LJ_TRI_CROSS(e1z, e0x, e1x, e0z), nz = LJ_TRI_CROSS(e1x, e0y, e1y, e0x);
+    float den = LJ_TRI_DOT(nx, ny, nz, r.dx, r.dy, r.dz);
     if (den == 0.0f) return false;
-    float T = (nx * ax + ny * ay) + nz * az;
+    float T = LJ_TRI_DOT(nx, ny, nz, ax, ay, az);
     float t = T / den;
     if (!(t > r.tnear && t <= tfar)) return false;
-    t_out = t; u_out = U / S; v_out = V / S;
+    float rS = 1.0f / S;
+    t_out = t; u_out = U * rS; v_out = V * rS;
     return true;
 }
 

@@ -176,7 +176,9 @@ __device__ __forceinline__ void trav_node_step(const TreeView &tv, LaneTrav &L) 
 }
 
 // one leaf: up to 8 primitives
-template <bool RESIDENT>
+// SPHERES: the scene holds sphere shapes (their test is the reference's double-precision callback; a scene without
+// spheres should not even carry its set-up code).
+template <bool RESIDENT, bool SPHERES>
 __device__ __forceinline__ void trav_leaf_step(const TreeView &tv, LaneTrav &L, const bool ANY_HIT) {
     const int code = ~L.cur;
     const int first = code >> 3, count = (code & 7) + 1;
@@ -187,7 +189,7 @@ __device__ __forceinline__ void trav_leaf_step(const TreeView &tv, LaneTrav &L, 
         if (RESIDENT || pi < tv.n_lprims) { const int S = tv.prim_stride; p0 = tv.lprims[pi]; p1 = tv.lprims[S + pi]; p2 = tv.lprims[2 * S + pi]; }
         else { p0 = tv.gprims[3 * pi]; p1 = tv.gprims[3 * pi + 1]; p2 = tv.gprims[3 * pi + 2]; }
         const int gprim = __float_as_int(p0.w), kind = __float_as_int(p1.w);
-        if (kind == 0) {
+        if (!SPHERES || kind == 0) {
             const float v0[3] = {p0.x, p0.y, p0.z}, v1[3] = {p1.x, p1.y, p1.z}, v2[3] = {p2.x, p2.y, p2.z};
             float t, u, v;
             if (tri_test(L.ray, L.best.t, v0, v1, v2, t, u, v)) {
@@ -209,7 +211,7 @@ __device__ __forceinline__ void trav_leaf_step(const TreeView &tv, LaneTrav &L, 
 // STATS: developer instrumentation (LJ_EXTEND_STATS=1): wave-level step counts and the lanes active in them, summed into
 // stats[0..7] = {outer iterations, sum of busy lanes, node steps, lanes in node steps, leaf prim rounds, lanes in them,
 // refills, rays}.  The production instantiation carries none of it.
-template <bool STATS, bool RESIDENT>
+template <bool STATS, bool RESIDENT, bool SPHERES>
 __global__ void __launch_bounds__(kBlock, 4) k_extend(DScene sc, DQueue q, const DBlockState *blocks, uint32_t seg, uint32_t *work, const uint32_t *chunk_list, uint32_t parity, int stack, int lds_nodes, int lds_prims, int *spill, uint32_t refill_min, uint32_t min_descending, unsigned long long *stats) {
     unsigned long long st_outer = 0, st_busy = 0, st_nodes = 0, st_node_lanes = 0, st_leaf = 0, st_leaf_lanes = 0, st_refill = 0, st_rays = 0;
     const TreeView tv = stage_tree(sc, stack, lds_nodes, lds_prims, spill, gridDim.x * kBlock, blockIdx.x * kBlock + threadIdx.x);
@@ -291,7 +293,7 @@ __global__ void __launch_bounds__(kBlock, 4) k_extend(DScene sc, DQueue q, const
             st_leaf += mx; st_leaf_lanes += sum;
         }
         // ... then all of them test their leaf together
-        if (busy && L.cur < 0) trav_leaf_step<RESIDENT>(tv, L, phase == 0);
+        if (busy && L.cur < 0) trav_leaf_step<RESIDENT, SPHERES>(tv, L, phase == 0);
         // ---- ray finished?
         if (STATS) st_rays += __popcll(__ballot(busy && L.cur == kDone));
         if (busy && L.cur == kDone) {
@@ -443,7 +445,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_rays(DScene sc, const RayIO *r
         trav_begin(L, rays[i].tnear, rays[i].tfar);
         while (L.cur != kDone) {
             while (L.cur >= 0 && L.cur != kDone) trav_node_step<false>(tv, L);
-            if (L.cur < 0) trav_leaf_step<false>(tv, L, occ != nullptr);
+            if (L.cur < 0) trav_leaf_step<false, true>(tv, L, occ != nullptr);
         }
         if (occ) occ[i] = L.best.gprim >= 0 ? 1 : 0;
         else {
@@ -462,10 +464,11 @@ __global__ void __launch_bounds__(kBlock) k_trace_rays(DScene sc, const RayIO *r
 // lane's stack live in LDS (1 KiB per level and workgroup); deeper levels — rare — go to a global overflow buffer.
 // LDS per 256-thread workgroup = stack * 1 KiB + staged nodes * 112 B + staged prims * 48 B; four workgroups share a
 // CU's 160 KiB, so the budget per workgroup is 40 KiB.
-struct ExtendConfig { int stack; int spill_levels; int lds_nodes; int lds_prims; int resident; size_t smem; uint32_t refill_min, min_descending; };
+struct ExtendConfig { int stack; int spill_levels; int lds_nodes; int lds_prims; int resident; int spheres; size_t smem; uint32_t refill_min, min_descending; };
 
-ExtendConfig extend_config(int n_nodes, int n_prims, int bvh_depth) {
+ExtendConfig extend_config(int n_nodes, int n_prims, int bvh_depth, int n_spheres) {
     ExtendConfig c;
+    c.spheres = n_spheres > 0 ? 1 : 0;
     const int need = 3 * (bvh_depth < 1 ? 1 : bvh_depth);
     c.stack = need < 16 ? need : 16;
     c.spill_levels = need - c.stack;
@@ -509,8 +512,17 @@ void launch_extend(const DScene &sc, const DQueue &q, const DBlockState *blocks,
     auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), cfg.smem, s, sc, q, blocks, seg, work, chunk_list, parity, cfg.stack, cfg.lds_nodes, cfg.lds_prims, spill, cfg.refill_min, cfg.min_descending, stats);
     };
-    if (stats) { if (cfg.resident) launch(k_extend<true, true>); else launch(k_extend<true, false>); }
-    else { if (cfg.resident) launch(k_extend<false, true>); else launch(k_extend<false, false>); }
+    const int variant = (stats ? 4 : 0) | (cfg.resident ? 2 : 0) | (cfg.spheres ? 1 : 0);
+    switch (variant) {
+        case 0: launch(k_extend<false, false, false>); break;
+        case 1: launch(k_extend<false, false, true>); break;
+        case 2: launch(k_extend<false, true, false>); break;
+        case 3: launch(k_extend<false, true, true>); break;
+        case 4: launch(k_extend<true, false, false>); break;
+        case 5: launch(k_extend<true, false, true>); break;
+        case 6: launch(k_extend<true, true, false>); break;
+        default: launch(k_extend<true, true, true>); break;
+    }
 }
 // shade_variant() returns the first (smallest) feature set that covers a scene
 int shade_variant(uint32_t kinds, bool textured, bool envmap, bool sphere_lights) {

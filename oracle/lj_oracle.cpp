@@ -266,9 +266,14 @@ struct PointAndNormal { Vector3 position, normal; };
 // These replace Embree's rtcIntersect1 / rtcOccluded1 kernels (intersection.cpp:32,83).  Plücker-coordinate
 // edge tests on origin-relative float vertices: the value computed for an edge is exactly negated for the
 // neighbouring triangle that shares it, so a ray cannot slip between two triangles (the property the reference
-// asks Embree for with RTC_SCENE_FLAG_ROBUST, scene.cpp:23).  Every operation is a single IEEE float op in the
-// written order; the HIP kernels repeat it verbatim.
+// asks Embree for with RTC_SCENE_FLAG_ROBUST, scene.cpp:23).  Every operation is a single IEEE float op (or an
+// explicit fused multiply-add) in the written order; the HIP kernels repeat it verbatim.
 struct Hit { float t, u, v; int shape_id, prim_id; long long gprim; double t_sphere; };
+// a*b - c*d and x*dx + y*dy + z*dz with explicit fused multiply-adds (IEEE fma is exactly specified, so the CPU oracle and
+// the GPU agree bit for bit).  Negating (a, c) negates the first exactly and negating (x, y, z) the second, which is what
+// keeps the edge tests of two triangles sharing an edge exact mirror images.
+#define LJ_TRI_CROSS(a, b, c, d) __builtin_fmaf((a), (b), -((c) * (d)))
+#define LJ_TRI_DOT(x, y, z, dx, dy, dz) __builtin_fmaf((z), (dz), __builtin_fmaf((y), (dy), (x) * (dx)))
 inline bool tri_test(const float o[3], const float d[3], float tnear, float tfar,
                      const float p0[3], const float p1[3], const float p2[3], float &t_out, float &u_out, float &v_out) {
     float ax = p0[0] - o[0], ay = p0[1] - o[1], az = p0[2] - o[2];
@@ -280,21 +285,22 @@ inline bool tri_test(const float o[3], const float d[3], float tnear, float tfar
     float s0x = cx + ax, s0y = cy + ay, s0z = cz + az;
     float s1x = ax + bx, s1y = ay + by, s1z = az + bz;
     float s2x = bx + cx, s2y = by + cy, s2z = bz + cz;
-    float U = (e0y * s0z - e0z * s0y) * d[0] + (e0z * s0x - e0x * s0z) * d[1] + (e0x * s0y - e0y * s0x) * d[2];
-    float V = (e1y * s1z - e1z * s1y) * d[0] + (e1z * s1x - e1x * s1z) * d[1] + (e1x * s1y - e1y * s1x) * d[2];
-    float W = (e2y * s2z - e2z * s2y) * d[0] + (e2z * s2x - e2x * s2z) * d[1] + (e2x * s2y - e2y * s2x) * d[2];
+    float U = LJ_TRI_DOT(LJ_TRI_CROSS(e0y, s0z, e0z, s0y), LJ_TRI_CROSS(e0z, s0x, e0x, s0z), LJ_TRI_CROSS(e0x, s0y, e0y, s0x), d[0], d[1], d[2]);
+    float V = LJ_TRI_DOT(LJ_TRI_CROSS(e1y, s1z, e1z, s1y), LJ_TRI_CROSS(e1z, s1x, e1x, s1z), LJ_TRI_CROSS(e1x, s1y, e1y, s1x), d[0], d[1], d[2]);
+    float W = LJ_TRI_DOT(LJ_TRI_CROSS(e2y, s2z, e2z, s2y), LJ_TRI_CROSS(e2z, s2x, e2x, s2z), LJ_TRI_CROSS(e2x, s2y, e2y, s2x), d[0], d[1], d[2]);
     float mn = fminf(fminf(U, V), W), mx = fmaxf(fmaxf(U, V), W);
     if (!(mn >= 0.0f || mx <= 0.0f)) return false;
     float S = (U + V) + W;
     if (S == 0.0f) return false;
     // Ng = (p1-p0) x (p2-p0) = e1 x e0 with e1 = a-b, e0 = c-a
-    float nx = e1y * e0z - e1z * e0y, ny = e1z * e0x - e1x * e0z, nz = e1x * e0y - e1y * e0x;
-    float den = (nx * d[0] + ny * d[1]) + nz * d[2];
+    float nx = LJ_TRI_CROSS(e1y, e0z, e1z, e0y), ny = LJ_TRI_CROSS(e1z, e0x, e1x, e0z), nz = LJ_TRI_CROSS(e1x, e0y, e1y, e0x);
+    float den = LJ_TRI_DOT(nx, ny, nz, d[0], d[1], d[2]);
     if (den == 0.0f) return false;
-    float T = (nx * ax + ny * ay) + nz * az;
+    float T = LJ_TRI_DOT(nx, ny, nz, ax, ay, az);
     float t = T / den;
     if (!(t > tnear && t <= tfar)) return false;
-    t_out = t; u_out = U / S; v_out = V / S;
+    float rS = 1.0f / S;
+    t_out = t; u_out = U * rS; v_out = V * rS;
     return true;
 }
 // sphere.inl:15-38 — the reference's own callback arithmetic: double maths on the float ray.
