@@ -166,7 +166,7 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
     const uint32_t n_slots = n_blocks * seg;
     ensure_queues(ctx, n_slots);
     // extend: persistent workgroups (as many as fit the GPU at once) that draw 256-slot chunks of the queue
-    uint32_t ext_per_cu = 4;
+    uint32_t ext_per_cu = 8;   // more than fit at once: the hardware keeps every CU as full as registers and LDS allow
     if (const char *e = getenv("LJ_TUNE_EXTEND_BLOCKS_PER_CU")) ext_per_cu = (uint32_t)std::max(1, atoi(e));
     const uint32_t n_chunks = n_slots / 256u;
     const uint32_t ext_grid = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)ctx->n_cus * ext_per_cu, (n_chunks + 3) / 4));
