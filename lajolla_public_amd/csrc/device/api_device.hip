@@ -22,6 +22,7 @@ int max_stack_depth();
 void launch_extend(const DScene &sc, const DQueue &q, const DBlockState *blocks, uint32_t grid, uint32_t seg, uint32_t *work, const uint32_t *chunk_list, uint32_t parity, const ExtendConfig &cfg, int *spill, unsigned long long *stats, hipStream_t s);
 void launch_shade(const DScene &sc, const DPass &pass, const DQueue &q, DBlockState *blocks, uint32_t n_blocks, uint32_t seg, const ShadeConfig &cfg, uint32_t *work, uint32_t *chunk_list, uint32_t parity, uint32_t extend_waves, hipStream_t s);
 void launch_resolve(const DPass &pass, uint32_t n_pixels, float *rgb, hipStream_t s);
+void launch_aux(const DScene &sc, const uint32_t *pixel_list, uint32_t n_pixels, int integrator, float *rgb, const ExtendConfig &cfg, int *spill, int grid, hipStream_t s);
 void launch_trace_rays(const DScene &sc, const void *rays, long long n, void *hits, unsigned char *occ, const ExtendConfig &cfg, int *spill, int grid, hipStream_t s);
 }
 
@@ -152,6 +153,21 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
     const uint64_t n_pix = plan.pixels.size();
     LjStats &st = sc->stats; st = LjStats{};
     if (n_pix == 0) return;
+    if (sc->flat.integrator != LJ_INTEGRATOR_PATH) {   // auxiliary buffers: one primary ray per pixel, no queue
+        if (samples_host) throw LjError(LJ_ERR_UNSUPPORTED, "the auxiliary integrators have one deterministic value per pixel, no per-sample values");
+        if (ctx->pixel_list.bytes < n_pix * 4) ctx->pixel_list.alloc(n_pix * 4);
+        HIP_CHECK(hipMemcpyAsync(ctx->pixel_list.p, plan.pixels.data(), n_pix * 4, hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipEventRecord(ctx->ev_begin, stream));
+        const int grid = (int)std::min<uint64_t>((n_pix + 255) / 256, (uint64_t)ctx->n_cus * 4);
+        ljd::launch_aux(sc->dscene, (const uint32_t *)ctx->pixel_list.p, (uint32_t)n_pix, sc->flat.integrator, rgb_dev, sc->ecfg,
+                        ensure_spill(ctx, sc->ecfg.spill_levels, (uint32_t)grid), grid, stream);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipEventRecord(ctx->ev_end, stream));
+        HIP_CHECK(hipEventSynchronize(ctx->ev_end));
+        float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
+        st.render_ms = ms; st.samples = n_pix; st.rays_closest = n_pix;
+        return;
+    }
     // pass size: keep the per-sample radiance buffer <= ~1.5 GiB and sample ids in 32 bits
     const uint64_t max_samples_pass = (uint64_t)1 << 27;
     uint64_t pix_per_pass = std::max<uint64_t>(1, max_samples_pass / (uint64_t)plan.spp);

@@ -161,6 +161,40 @@ LJ_HD DVertex build_vertex(const DScene &sc, f3 org, f3 dir, float t, float bu, 
     return vx;
 }
 
+// ------------------------------------------------------------------ auxiliary buffers (render.cpp:12-69 aux_render)
+// The value of one pixel for the Depth / ShadingNormal / MeanCurvature / RayDifferential / MipmapLevel "integrators":
+// one primary ray through the pixel centre, no random numbers.  `integrator` uses the LJ_INTEGRATOR_* numbering (0..4).
+LJ_HD f3 aux_value(const DScene &sc, int integrator, f3 org, f3 dir, float t, float bu, float bv, int gprim) {
+    if (gprim < 0) return mk3(0, 0, 0);
+    const DVertex vx = build_vertex(sc, org, dir, t, bu, bv, gprim, sc.init_spread);
+    const DPrimShade &ps = sc.prims[gprim];
+    if (integrator == 0) { float d = length(vx.position - org); return mk3(d, d, d); }
+    if (integrator == 1) return vx.frame.n;
+    if (integrator == 2) {  // triangle_mesh.inl:128-146, sphere.inl:258
+        float k = 0.0f;
+        if (vx.is_sphere) k = 1.0f / ps.n1[0];
+        else if (ps.flags & 2) {
+            // the uv determinant cancels badly on nearly degenerate uv maps: double, as the reference has it
+            const double dus = (double)ps.uv2[0] - ps.uv0[0], dvs = (double)ps.uv2[1] - ps.uv0[1], dut = (double)ps.uv2[0] - ps.uv1[0], dvt = (double)ps.uv2[1] - ps.uv1[1];
+            const double det = dus * dvt - dut * dvs;
+            const float dsdu = (float)(dvt / det), dtdu = (float)(-dvs / det), dsdv = (float)(dut / det), dtdv = (float)(-dus / det);
+            const f3 dnds = ld3(ps.n2) - ld3(ps.n0), dndt = ld3(ps.n2) - ld3(ps.n1);
+            const f3 dndu = dnds * dsdu + dndt * dtdu, dndv = dnds * dsdv + dndt * dtdv;
+            k = (dot(dndu, vx.frame.x) + dot(dndv, vx.frame.y)) * 0.5f;
+        }
+        return mk3(k, k, k);
+    }
+    if (integrator == 3) return mk3(0.0f, sc.init_spread, 0.0f);   // init_ray_differential (ray.h:35-37): radius 0
+    // MipmapLevel: only for an image texture in the material's get_texture() slot (materials/*.inl get_texture_op)
+    const DMaterial &m = sc.materials[vx.material_id];
+    if (m.kind == 6 || m.tex[0].kind != 1) return mk3(0, 0, 0);
+    const DTexture &tx = m.tex[0];
+    const DImage &img = sc.images3[tx.texture_id];
+    const float scaled = (float)(img.lv[0].w > img.lv[0].h ? img.lv[0].w : img.lv[0].h) * fmaxf(tx.uscale, tx.vscale) * vx.uv_screen_size;
+    const float level = log2f(fmaxf(scaled, 1e-8f));
+    return mk3(level, level, level);
+}
+
 // ------------------------------------------------------------------ lights (lights/*.inl, shapes/*.inl sampling)
 struct LightSample { f3 position, normal; };
 

@@ -462,6 +462,26 @@ __global__ void __launch_bounds__(kBlock) k_trace_rays(DScene sc, const RayIO *r
     }
 }
 
+// ---------------------------------------------------------------- auxiliary buffers (render.cpp:12-69)
+// One thread per listed pixel: primary ray through the pixel centre, closest hit, aux_value().
+__global__ void __launch_bounds__(kBlock) k_aux(DScene sc, const uint32_t *pixel_list, uint32_t n_pixels, int integrator, float *rgb, int stack, int lds_nodes, int lds_prims, int *spill) {
+    const TreeView tv = stage_tree(sc, stack, lds_nodes, lds_prims, spill, gridDim.x * kBlock, blockIdx.x * kBlock + threadIdx.x);
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_pixels; i += gridDim.x * kBlock) {
+        const uint32_t pixel = pixel_list[i];
+        const int x = (int)(pixel % (uint32_t)sc.cam.width), y = (int)(pixel / (uint32_t)sc.cam.width);
+        const f3 org = ld3(sc.cam.org), dir = camera_primary_dir(sc.cam, x, y, 0.5f, 0.5f);
+        LaneTrav L;
+        L.ray.ox = org.x; L.ray.oy = org.y; L.ray.oz = org.z; L.ray.dx = dir.x; L.ray.dy = dir.y; L.ray.dz = dir.z;
+        trav_begin(L, 0.0f, INFINITY);   // camera.cpp:46: tnear 0
+        while (L.cur != kDone) {
+            while (L.cur >= 0 && L.cur != kDone) trav_node_step<false>(tv, L);
+            if (L.cur < 0) trav_leaf_step<false, true>(tv, L, false);
+        }
+        const f3 c = aux_value(sc, integrator, org, dir, L.best.t, L.best.u, L.best.v, L.best.gprim);
+        rgb[3ull * pixel] = c.x; rgb[3ull * pixel + 1] = c.y; rgb[3ull * pixel + 2] = c.z;
+    }
+}
+
 // ---------------------------------------------------------------- launchers (called from api_device.hip)
 // A traversal of a BVH4 with `depth` inner levels holds at most 3 * depth entries.  The first `stack` levels of every
 // lane's stack live in LDS (1 KiB per level and workgroup); deeper levels — rare — go to a global overflow buffer.
@@ -552,6 +572,9 @@ void launch_resolve(const DPass &pass, uint32_t n_pixels, float *rgb, hipStream_
     const uint32_t waves_per_block = kBlock / 64;
     const uint32_t grid = (n_pixels + waves_per_block - 1) / waves_per_block;
     if (grid) hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(kBlock), 0, s, pass, n_pixels, rgb);
+}
+void launch_aux(const DScene &sc, const uint32_t *pixel_list, uint32_t n_pixels, int integrator, float *rgb, const ExtendConfig &cfg, int *spill, int grid, hipStream_t s) {
+    if (n_pixels) hipLaunchKernelGGL(k_aux, dim3(grid), dim3(kBlock), cfg.smem, s, sc, pixel_list, n_pixels, integrator, rgb, cfg.stack, cfg.lds_nodes, cfg.lds_prims, spill);
 }
 void launch_trace_rays(const DScene &sc, const void *rays, long long n, void *hits, unsigned char *occ, const ExtendConfig &cfg, int *spill, int grid, hipStream_t s) {
     hipLaunchKernelGGL(k_trace_rays, dim3(grid), dim3(kBlock), cfg.smem, s, sc, (const RayIO *)rays, n, (HitIO *)hits, occ, cfg.stack, cfg.lds_nodes, cfg.lds_prims, spill);

@@ -82,8 +82,8 @@ ljd::DScene FlatScene::host_view() const {
 
 FlatScene flatten_scene(const LjSceneDesc &d) {
     FlatScene F;
-    if (d.options.integrator != LJ_INTEGRATOR_PATH)
-        throw LjError(LJ_ERR_UNSUPPORTED, "only the `path` integrator (path_tracing.h) runs on the device; integrator id " + std::to_string(d.options.integrator) + " is not implemented");
+    if (d.options.integrator < LJ_INTEGRATOR_DEPTH || d.options.integrator > LJ_INTEGRATOR_PATH)
+        throw LjError(LJ_ERR_UNSUPPORTED, "the `path` integrator (path_tracing.h) and the auxiliary buffers (render.cpp:12-69) run on the device; integrator id " + std::to_string(d.options.integrator) + " (volpath) is not implemented");
     F.integrator = d.options.integrator; F.spp = d.options.samples_per_pixel; F.max_depth = d.options.max_depth; F.rr_depth = d.options.rr_depth;
     F.envmap_light_id = d.envmap_light_id;
     // ---- camera

@@ -1406,6 +1406,31 @@ OScene *scene_create(const LjSceneDesc *d) {
 } // namespace
 
 // =================================================================== C entry points for the tests (ctypes)
+// render.cpp:12-69 aux_render: one primary ray through the pixel centre, no RNG
+static Vector3 aux_pixel(const OScene &s, int x, int y, Counters *cnt) {
+    const int w = s.d.camera.width, h = s.d.camera.height;
+    Ray ray = sample_primary(s, Vector2{(x + Real(0.5)) / w, (y + Real(0.5)) / h});
+    RayDifferential ray_diff{Real(0), Real(0.25) / std::max(w, h)};
+    PathVertex vertex;
+    if (!intersect(s, ray, ray_diff, vertex, cnt)) return {0, 0, 0};
+    switch (s.d.options.integrator) {
+        case LJ_INTEGRATOR_DEPTH: { Real d = distance(vertex.position, ray.org); return {d, d, d}; }
+        case LJ_INTEGRATOR_SHADING_NORMAL: return vertex.shading_frame.n;
+        case LJ_INTEGRATOR_MEAN_CURVATURE: return {vertex.mean_curvature, vertex.mean_curvature, vertex.mean_curvature};
+        case LJ_INTEGRATOR_RAY_DIFFERENTIAL: return {ray_diff.radius, ray_diff.spread, Real(0)};
+        default: {  // MipmapLevel: only when get_texture(material) (materials/*.inl get_texture_op) is an image texture
+            const LjMaterial &m = s.d.materials[vertex.material_id];
+            if (m.kind == LJ_MAT_DISNEYCLEARCOAT) return {0, 0, 0};  // disney_clearcoat.inl:108-110: a constant texture
+            const LjTexture &t = m.tex[0];
+            if (t.kind != LJ_TEX_IMAGE) return {0, 0, 0};
+            const Mip &img = s.mips3[t.texture_id];
+            Real scaled_footprint = std::max(img.w[0], img.h[0]) * std::max(t.uscale, t.vscale) * vertex.uv_screen_size;
+            Real level = std::log2(std::max(scaled_footprint, Real(1e-8f)));
+            return {level, level, level};
+        }
+    }
+}
+
 extern "C" {
 
 void *oracle_scene_create(const LjSceneDesc *d) { return scene_create(d); }
@@ -1600,6 +1625,12 @@ int oracle_render(void *sv, const OracleRenderArgs *a, double *rgb, double *per_
                 bool inside = x >= cx0 && x < cx1 && y >= cy0 && y < cy1;
                 if (!inside && a->rng_mode == 0) continue;
                 Spectrum radiance{0, 0, 0};
+                if (s->d.options.integrator != LJ_INTEGRATOR_PATH) {  // aux buffers: one deterministic value per pixel
+                    if (!inside) continue;
+                    Vector3 c = aux_pixel(*s, x, y, &cnt);
+                    size_t o = ((size_t)y * w + x) * 3; rgb[o] = c.x; rgb[o + 1] = c.y; rgb[o + 2] = c.z;
+                    continue;
+                }
                 for (int sidx = 0; sidx < spp; sidx++) {
                     int st = 0;
                     if (a->rng_mode == 0) rng = init_pcg32(((uint64_t)y * w + x) * (uint64_t)spp + sidx, seed);

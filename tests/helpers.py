@@ -199,6 +199,12 @@ class Twin:
                                      out.ctypes.data_as(C.c_void_p), C.byref(b))
         return out, b.value
 
+    def aux(self, integrator, crop):
+        x0, y0, x1, y1 = crop
+        out = np.zeros((y1 - y0, x1 - x0, 3), np.float32)
+        self.lib.twin_aux(self.h, C.c_int(integrator), C.c_int(x0), C.c_int(y0), C.c_int(x1), C.c_int(y1), out.ctypes.data_as(C.c_void_p))
+        return out
+
     def bsdf(self, material_id, vertex22, dir_in, dir_out, rnd_uv, rnd_w):
         ev, sd = np.zeros(3, np.float32), np.zeros(3, np.float32)
         pdf, eta, rough = C.c_float(), C.c_float(), C.c_float()

@@ -119,6 +119,22 @@ void twin_render_samples(void *tv, int spp, int max_depth, int use_max_depth, ui
     if (bounces_out) *bounces_out = b;
 }
 
+// the auxiliary "integrators" (k_aux): one value per pixel of the crop window, float[ch][cw][3]
+void twin_aux(void *tv, int integrator, int x0, int y0, int x1, int y1, float *out) {
+    Twin *t = (Twin *)tv;
+    const DScene &sc = t->view;
+    HostMem mem(sc);
+    for (int y = y0; y < y1; y++) for (int x = x0; x < x1; x++) {
+        const f3 org = ld3(sc.cam.org), dir = camera_primary_dir(sc.cam, x, y, 0.5f, 0.5f);
+        RayF ray; ray.ox = org.x; ray.oy = org.y; ray.oz = org.z; ray.dx = dir.x; ray.dy = dir.y; ray.dz = dir.z; ray.tnear = 0.0f; ray.tfar = INFINITY;
+        HitRec h;
+        traverse<false>(mem, ray, h);
+        const f3 c = aux_value(sc, integrator, org, dir, h.t, h.u, h.v, h.gprim);
+        float *o = out + 3 * ((size_t)(y - y0) * (x1 - x0) + (x - x0));
+        o[0] = c.x; o[1] = c.y; o[2] = c.z;
+    }
+}
+
 // device BSDF code on an explicit vertex (same record layout as oracle_bsdf's vertex22), for KAT-level comparisons
 void twin_bsdf(void *tv, int material_id, const double *vx22, const double *dir_in, const double *dir_out, const double *rnd_uv, double rnd_w,
                float *eval3, float *pdf, int *sample_valid, float *sample_dir3, float *sample_eta, float *sample_roughness) {
