@@ -145,10 +145,12 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "Msamples/sec (whole node), cbox 256spp", "value": round(value, 2), "unit": "Msamples/s",
+            "metric": "Msamples/sec (whole node), cbox 256spp" if (os.path.basename(args.scene) == "cbox.xml" and spp == 256)
+                      else f"Msamples/sec (whole node), {os.path.basename(args.scene)} {spp}spp",
+            "value": round(value, 2), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "scene file shipped with the reference (scenes/cbox/cbox.xml), sampleCount overridden to %d" % spp,
-            "config": {"workload": f"cbox.xml {w}x{h} @ {spp} spp, path integrator (Lambertian + area light, max_depth -1, rr_depth 5)",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "scene file shipped with the reference (scenes/%s), sampleCount overridden to %d" % (os.path.relpath(args.scene, os.path.join(ROOT, "scenes")), spp),
+            "config": {"workload": f"{os.path.basename(args.scene)} {w}x{h} @ {spp} spp, path integrator" + (" (Lambertian + area light, max_depth -1, rr_depth 5)" if os.path.basename(args.scene) == "cbox.xml" else f" (max_depth {hs.desc.options.max_depth}, rr_depth {hs.desc.options.rr_depth})"),
                        "samples_per_step": total_samples, "mean_bounce_iterations_K": round(k_mean, 4),
                        "rng": "pcg32, one stream per (pixel, sample), seed 0x853c49e6748fea9b",
                        "parallelism": f"tiles%{world}" if world > 1 else "1 GPU", "collective": "RCCL reduce(sum) of the float framebuffer" if world > 1 else "none"},
