@@ -54,6 +54,8 @@ constexpr uint32_t kMaxBlocks = 8192;
 struct lj_context {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t lane_streams[3] = {nullptr, nullptr, nullptr};   // further lanes of a render (run_render)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int n_cus = 256;
     // workspace, grown on demand and reused across renders
     DevBuf queue_mem; uint32_t queue_capacity = 0;
@@ -177,32 +179,52 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
     uint32_t pool = (uint32_t)std::min<uint64_t>(plan.pool, std::max<uint64_t>(pass_samples_max, 256));
     uint32_t blocks_per_cu = 8;
     if (const char *e = getenv("LJ_TUNE_BLOCKS_PER_CU")) blocks_per_cu = (uint32_t)std::max(1, atoi(e));
-    uint32_t n_blocks = std::min<uint32_t>(kMaxBlocks, std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)ctx->n_cus * blocks_per_cu, pool / 256)));
-    uint32_t seg = ((pool + n_blocks - 1) / n_blocks + 255u) & ~255u;
-    const uint32_t n_slots = n_blocks * seg;
-    ensure_queues(ctx, n_slots);
-    // extend: persistent workgroups (as many as fit the GPU at once) that draw 256-slot chunks of the queue
-    uint32_t ext_per_cu = 8;   // more than fit at once: the hardware keeps every CU as full as registers and LDS allow
-    if (const char *e = getenv("LJ_TUNE_EXTEND_BLOCKS_PER_CU")) ext_per_cu = (uint32_t)std::max(1, atoi(e));
-    const uint32_t n_chunks = n_slots / 256u;
-    const uint32_t ext_grid = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)ctx->n_cus * ext_per_cu, (n_chunks + 3) / 4));
-    int *spill = ensure_spill(ctx, sc->ecfg.spill_levels, ext_grid);
-    // work[0] = the extend kernel's draw counter, work[1 + parity] = number of listed chunks; two chunk lists, used
-    // alternately, so that a shade launch can append to one while nothing reads it
-    if (!ctx->chunk_counter.p) ctx->chunk_counter.alloc(64);
-    if (ctx->chunk_list.bytes < (size_t)n_chunks * 8) ctx->chunk_list.alloc((size_t)n_chunks * 8);
-    uint32_t *work = (uint32_t *)ctx->chunk_counter.p;
-    uint32_t *chunk_lists[2] = {(uint32_t *)ctx->chunk_list.p, (uint32_t *)ctx->chunk_list.p + n_chunks};
-    uint32_t parity = 0;
+    // Two lanes: the pool, its workgroup segments and the pass's samples are split in two halves that advance
+    // independently on two streams.  The extend kernel is bound by VALU issue and moves few bytes, the shade kernel
+    // streams the queue and leaves the VALUs mostly idle; with two lanes the GPU usually has one of each to run side by
+    // side.  (One lane when kernels are timed individually, for tiny renders, or on request.)
     // developer instrumentation of the extend kernel (utilisation counters printed to stderr); off unless asked for
     unsigned long long *xstats = nullptr;
     DevBuf xstats_buf;
     if (getenv("LJ_EXTEND_STATS")) { xstats_buf.alloc(64); HIP_CHECK(hipMemsetAsync(xstats_buf.p, 0, 64, stream)); xstats = (unsigned long long *)xstats_buf.p; }
-    ljd::DQueue q = carve_queue(ctx->queue_mem.p, ctx->queue_capacity);
+    uint32_t n_lanes = (timing || xstats || pool < (1u << 20)) ? 1u : 2u;
+    if (const char *e = getenv("LJ_TUNE_LANES")) n_lanes = (uint32_t)std::min(4, std::max(1, atoi(e)));
+    uint32_t n_blocks = std::min<uint32_t>(kMaxBlocks, std::max<uint32_t>(n_lanes, std::min<uint32_t>((uint32_t)ctx->n_cus * blocks_per_cu, pool / 256)));
+    n_blocks = (n_blocks / n_lanes) * n_lanes;
+    const uint32_t lane_blocks = n_blocks / n_lanes;
+    uint32_t seg = ((pool + n_blocks - 1) / n_blocks + 255u) & ~255u;
+    const uint32_t n_slots = n_blocks * seg, lane_slots = lane_blocks * seg;
+    ensure_queues(ctx, n_slots);
+    // extend: persistent workgroups that draw 256-slot chunks of the queue.  One lane: more workgroups than fit at once, so
+    // the hardware keeps every CU as full as registers and LDS allow; two lanes: few enough that the other lane's shade
+    // workgroups find room beside them.
+    uint32_t ext_per_cu = n_lanes == 1 ? 8 : 4;
+    if (const char *e = getenv("LJ_TUNE_EXTEND_BLOCKS_PER_CU")) ext_per_cu = (uint32_t)std::max(1, atoi(e));
+    const uint32_t lane_chunks = lane_slots / 256u;
+    const uint32_t ext_grid = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)ctx->n_cus * ext_per_cu, (lane_chunks + 3) / 4));
+    int *spill_base = ensure_spill(ctx, sc->ecfg.spill_levels, ext_grid * n_lanes);
+    // per lane: work[0] = the extend kernel's draw counter, work[1 + parity] = number of listed chunks; two chunk lists, used
+    // alternately, so that a shade launch can append to one while nothing reads it
+    if (!ctx->chunk_counter.p) ctx->chunk_counter.alloc(512);
+    if (ctx->chunk_list.bytes < (size_t)lane_chunks * 8 * n_lanes) ctx->chunk_list.alloc((size_t)lane_chunks * 8 * n_lanes);
+    const ljd::DQueue q_all = carve_queue(ctx->queue_mem.p, ctx->queue_capacity);
+    struct Lane {
+        hipStream_t stream; ljd::DQueue q; ljd::DBlockState *dblocks; ljd::DBlockState *hblocks;
+        uint32_t *work; uint32_t *lists[2]; uint32_t parity; int *spill; bool done; int batch;
+    } lanes[4];
+    for (uint32_t l = 0; l < n_lanes; l++) {
+        Lane &L = lanes[l];
+        L.stream = l == 0 ? stream : ctx->lane_streams[l - 1];
+        const size_t o = (size_t)l * lane_slots;
+        L.q = q_all; L.q.ro += o; L.q.rd += o; L.q.rs += o; L.q.rh += o; L.q.rw += o; L.q.rl += o; L.q.rn += o; L.q.rg += o;
+        L.dblocks = (ljd::DBlockState *)ctx->blocks.p + (size_t)l * lane_blocks; L.hblocks = ctx->blocks_host + (size_t)l * lane_blocks;
+        L.work = (uint32_t *)ctx->chunk_counter.p + 32 * l;
+        L.lists[0] = (uint32_t *)ctx->chunk_list.p + (size_t)l * 2 * lane_chunks; L.lists[1] = L.lists[0] + lane_chunks;
+        L.spill = spill_base ? spill_base + (size_t)l * sc->ecfg.spill_levels * ext_grid * 256 : nullptr;
+    }
     if (ctx->sample_rgb.bytes < pass_samples_max * 12) ctx->sample_rgb.alloc(pass_samples_max * 12);
     if (ctx->pixel_list.bytes < n_pix * 4) ctx->pixel_list.alloc(n_pix * 4);
     HIP_CHECK(hipMemcpyAsync(ctx->pixel_list.p, plan.pixels.data(), n_pix * 4, hipMemcpyHostToDevice, stream));
-    ljd::DBlockState *dblocks = (ljd::DBlockState *)ctx->blocks.p;
     HIP_CHECK(hipEventRecord(ctx->ev_begin, stream));
     double extend_ms = 0, shade_ms = 0;
     for (uint64_t p0 = 0; p0 < n_pix; p0 += pix_per_pass) {
@@ -220,38 +242,59 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
                 bs.next_sample = (uint32_t)lo; bs.end_sample = (uint32_t)hi;
                 ctx->blocks_host[b] = bs;
             }
-            HIP_CHECK(hipMemcpyAsync(dblocks, ctx->blocks_host, sizeof(ljd::DBlockState) * n_blocks, hipMemcpyHostToDevice, stream));
+            HIP_CHECK(hipMemcpyAsync(ctx->blocks.p, ctx->blocks_host, sizeof(ljd::DBlockState) * n_blocks, hipMemcpyHostToDevice, stream));
+        }
+        HIP_CHECK(hipMemsetAsync(ctx->chunk_counter.p, 0, 512, stream));
+        if (n_lanes > 1) {  // the second lane starts once the pass's inputs are in place
+            HIP_CHECK(hipEventRecord(ctx->ev_fork, stream));
+            for (uint32_t l = 1; l < n_lanes; l++) HIP_CHECK(hipStreamWaitEvent(ctx->lane_streams[l - 1], ctx->ev_fork, 0));
         }
         // step 0 is a shade over empty segments: it only generates camera rays
-        HIP_CHECK(hipMemsetAsync(work, 0, 64, stream));
-        parity = 0;
-        ljd::launch_shade(ds, pass, q, dblocks, n_blocks, seg, sc->scfg, work, chunk_lists[parity], parity, ext_grid * 4u, stream);
-        bool done = false;
-        int batch = 8;  // steps per host round trip; all per-step state lives on the device
-        for (int guard = 0; guard < (1 << 20) && !done; guard++) {
-            for (int b = 0; b < batch; b++) {
-                if (timing) HIP_CHECK(hipEventRecord(ctx->ev_k0, stream));
-                ljd::launch_extend(ds, q, dblocks, ext_grid, seg, work, chunk_lists[parity], parity, sc->ecfg, spill, xstats, stream);
-                if (timing) HIP_CHECK(hipEventRecord(ctx->ev_k1, stream));
-                parity ^= 1u;
-                ljd::launch_shade(ds, pass, q, dblocks, n_blocks, seg, sc->scfg, work, chunk_lists[parity], parity, ext_grid * 4u, stream);
-                if (timing) {
-                    HIP_CHECK(hipEventRecord(ctx->ev_end, stream));
-                    HIP_CHECK(hipEventSynchronize(ctx->ev_end));
-                    float a = 0, c = 0;
-                    HIP_CHECK(hipEventElapsedTime(&a, ctx->ev_k0, ctx->ev_k1)); HIP_CHECK(hipEventElapsedTime(&c, ctx->ev_k1, ctx->ev_end));
-                    extend_ms += a; shade_ms += c;
+        for (uint32_t l = 0; l < n_lanes; l++) {
+            Lane &L = lanes[l];
+            L.parity = 0; L.done = false; L.batch = 8;  // steps per host round trip; all per-step state lives on the device
+            ljd::launch_shade(ds, pass, L.q, L.dblocks, lane_blocks, seg, sc->scfg, L.work, L.lists[0], 0, ext_grid * 4u, L.stream);
+        }
+        // Round-robin over the lanes: look at a lane's block states only when its previous batch has drained, and give it
+        // its next batch at once, so the other lane's kernels keep the GPU busy during this lane's host round trip.
+        bool pending[4] = {false, false, false, false};
+        for (int guard = 0; guard < (1 << 21); guard++) {
+            bool any = false;
+            for (uint32_t l = 0; l < n_lanes; l++) {
+                Lane &L = lanes[l];
+                if (L.done) continue;
+                if (pending[l]) {
+                    HIP_CHECK(hipStreamSynchronize(L.stream));
+                    pending[l] = false;
+                    uint64_t alive = 0;
+                    for (uint32_t b = 0; b < lane_blocks; b++) alive += L.hblocks[b].count;
+                    L.done = alive == 0;
+                    // the long tail (a few deep paths left): launches are nearly empty, so look less often
+                    L.batch = alive * 64ull < (uint64_t)lane_slots ? 16 : 8;
+                    if (L.done) continue;
                 }
-                st.extend_launches++; st.shade_launches++; st.wavefront_steps++;
+                any = true;
+                for (int b = 0; b < L.batch; b++) {
+                    if (timing) HIP_CHECK(hipEventRecord(ctx->ev_k0, L.stream));
+                    ljd::launch_extend(ds, L.q, L.dblocks, ext_grid, seg, L.work, L.lists[L.parity], L.parity, sc->ecfg, L.spill, xstats, L.stream);
+                    if (timing) HIP_CHECK(hipEventRecord(ctx->ev_k1, L.stream));
+                    L.parity ^= 1u;
+                    ljd::launch_shade(ds, pass, L.q, L.dblocks, lane_blocks, seg, sc->scfg, L.work, L.lists[L.parity], L.parity, ext_grid * 4u, L.stream);
+                    if (timing) {
+                        HIP_CHECK(hipEventRecord(ctx->ev_end, L.stream));
+                        HIP_CHECK(hipEventSynchronize(ctx->ev_end));
+                        float a = 0, c = 0;
+                        HIP_CHECK(hipEventElapsedTime(&a, ctx->ev_k0, ctx->ev_k1)); HIP_CHECK(hipEventElapsedTime(&c, ctx->ev_k1, ctx->ev_end));
+                        extend_ms += a; shade_ms += c;
+                    }
+                    st.extend_launches++; st.shade_launches++;
+                    if (l == 0) st.wavefront_steps++;
+                }
+                HIP_CHECK(hipGetLastError());
+                HIP_CHECK(hipMemcpyAsync(L.hblocks, L.dblocks, sizeof(ljd::DBlockState) * lane_blocks, hipMemcpyDeviceToHost, L.stream));
+                pending[l] = true;
             }
-            HIP_CHECK(hipGetLastError());
-            HIP_CHECK(hipMemcpyAsync(ctx->blocks_host, dblocks, sizeof(ljd::DBlockState) * n_blocks, hipMemcpyDeviceToHost, stream));
-            HIP_CHECK(hipStreamSynchronize(stream));
-            uint64_t alive = 0;
-            for (uint32_t b = 0; b < n_blocks; b++) alive += ctx->blocks_host[b].count;
-            done = alive == 0;
-            // the long tail (a few deep paths left): launches are nearly empty, so look less often
-            batch = alive * 64ull < (uint64_t)n_slots ? 16 : 8;
+            if (!any) break;
         }
         uint64_t samples_done = 0, path_steps = 0;
         for (uint32_t b = 0; b < n_blocks; b++) {
@@ -266,6 +309,7 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
         // shade reads 7 records (112 B) and writes 7 records (112 B) per live path-step, plus 12 B per finished sample
         st.extend_bytes += path_steps * 64ull;
         st.shade_bytes += path_steps * 224ull + total * 12ull;
+        // (both lanes were synchronised with the host above, so the caller's stream may read what the second lane wrote)
         if (rgb_dev) ljd::launch_resolve(pass, (uint32_t)np, rgb_dev, stream);
         if (samples_host) {
             HIP_CHECK(hipMemcpyAsync(samples_host + p0 * (uint64_t)plan.spp * 3, ctx->sample_rgb.p, total * 12, hipMemcpyDeviceToHost, stream));
@@ -305,6 +349,8 @@ int lj_context_create(int device_id, lj_context **out) {
             throw LjError(LJ_ERR_DEVICE, std::string("device is ") + prop.gcnArchName + "; this build contains gfx950 code objects only");
         ctx->n_cus = prop.multiProcessorCount;
         HIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        for (auto &ls : ctx->lane_streams) HIP_CHECK(hipStreamCreateWithFlags(&ls, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
         ctx->blocks.alloc(sizeof(ljd::DBlockState) * kMaxBlocks);
         HIP_CHECK(hipHostMalloc((void **)&ctx->blocks_host, sizeof(ljd::DBlockState) * kMaxBlocks, hipHostMallocDefault));
         HIP_CHECK(hipEventCreate(&ctx->ev_begin)); HIP_CHECK(hipEventCreate(&ctx->ev_end));
@@ -317,6 +363,9 @@ void lj_context_destroy(lj_context *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
+    for (auto &ls : ctx->lane_streams) if (ls) { (void)hipStreamSynchronize(ls); (void)hipStreamDestroy(ls); }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->blocks_host) (void)hipHostFree(ctx->blocks_host);
     for (hipEvent_t e : {ctx->ev_begin, ctx->ev_end, ctx->ev_k0, ctx->ev_k1}) if (e) (void)hipEventDestroy(e);
     delete ctx;
