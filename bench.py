@@ -36,11 +36,13 @@ def host_cores():
 
 def profiled_traffic(kernel, launches):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same workload
-    (profiles/r01_hbm_traffic.json, written by tools/prof_bench.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md)."""
+    (profiles/r01_hbm_traffic.json, written by tools/prof_bench.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md).
+    The counters are totals over one render — the same bytes however the render is cut into launches — so they are
+    divided by the launch count of the instrumented pass the roofline figures come from."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
         k = t["kernels"][kernel]
-        return int((k["fetch_bytes"] + k["write_bytes"]) / max(k["launches"], 1)), t["source"]
+        return int((k["fetch_bytes"] + k["write_bytes"]) / max(launches, 1)), t["source"]
     except (OSError, KeyError, ValueError):
         return None, None
 
