@@ -22,7 +22,9 @@ struct RayF { float ox, oy, oz, dx, dy, dz, tnear, tfar; };
 #define LJ_TRI_CROSS(a, b, c, d) __builtin_fmaf((a), (b), -((c) * (d)))
 #define LJ_TRI_DOT(x, y, z, dx, dy, dz) __builtin_fmaf((z), (dz), __builtin_fmaf((y), (dy), (x) * (dx)))
 // Plücker-coordinate edge tests on origin-relative vertices; see oracle/lj_oracle.cpp tri_test for the rationale.
-LJ_HD bool tri_test(const RayF &r, float tfar, const float *p0, const float *p1, const float *p2, float &t_out, float &u_out, float &v_out) {
+// `tri_test_raw` stops before the barycentric division: it returns t and the unnormalised (U, V, S); u = U * (1 / S),
+// v = V * (1 / S).  A traversal keeps (U, V, S) of its closest hit and divides once per ray, not once per accepted hit.
+LJ_HD bool tri_test_raw(const RayF &r, float tfar, const float *p0, const float *p1, const float *p2, float &t_out, float &U_out, float &V_out, float &S_out) {
     float ax = p0[0] - r.ox, ay = p0[1] - r.oy, az = p0[2] - r.oz;
     float bx = p1[0] - r.ox, by = p1[1] - r.oy, bz = p1[2] - r.oz;
     float cx = p2[0] - r.ox, cy = p2[1] - r.oy, cz = p2[2] - r.oz;
@@ -45,8 +47,14 @@ LJ_HD bool tri_test(const RayF &r, float tfar, const float *p0, const float *p1,
     float T = LJ_TRI_DOT(nx, ny, nz, ax, ay, az);
     float t = T / den;
     if (!(t > r.tnear && t <= tfar)) return false;
-    float rS = 1.0f / S;
-    t_out = t; u_out = U * rS; v_out = V * rS;
+    t_out = t; U_out = U; V_out = V; S_out = S;
+    return true;
+}
+LJ_HD bool tri_test(const RayF &r, float tfar, const float *p0, const float *p1, const float *p2, float &t_out, float &u_out, float &v_out) {
+    float U, V, S;
+    if (!tri_test_raw(r, tfar, p0, p1, p2, t_out, U, V, S)) return false;
+    const float rS = 1.0f / S;
+    u_out = U * rS; v_out = V * rS;
     return true;
 }
 

@@ -89,16 +89,19 @@ constexpr int kDone = 0x7fffffff;  // "no more work for this ray" marker in `cur
 
 struct LaneTrav {
     RayF ray; float ix, iy, iz;
-    HitRec best;
+    HitRec best;     // for a triangle hit u, v hold the unnormalised barycentrics U, V until trav_finish divides by best_S
+    float best_S;
     int cur, sp;
     uint32_t nqx, nqy, nqz;  // quarter index (0..5) holding the NEAR plane of each axis for this ray's direction signs
 };
 
 __device__ __forceinline__ void trav_begin(LaneTrav &L, float tnear, float tfar) {
     L.ray.tnear = tnear; L.ray.tfar = tfar;
-    L.ix = 1.0f / L.ray.dx; L.iy = 1.0f / L.ray.dy; L.iz = 1.0f / L.ray.dz;
+    // v_rcp_f32 (1 ulp) is enough here: the slabs only steer the traversal, and the boxes carry a 1e-5 pad plus a 4-ulp
+    // widening of the exit distance; hits are decided by the primitive tests alone
+    L.ix = __builtin_amdgcn_rcpf(L.ray.dx); L.iy = __builtin_amdgcn_rcpf(L.ray.dy); L.iz = __builtin_amdgcn_rcpf(L.ray.dz);
     L.nqx = L.ix < 0.0f ? 3u : 0u; L.nqy = L.iy < 0.0f ? 4u : 1u; L.nqz = L.iz < 0.0f ? 5u : 2u;
-    L.best.t = tfar; L.best.u = 0.0f; L.best.v = 0.0f; L.best.gprim = -1;
+    L.best.t = tfar; L.best.u = 0.0f; L.best.v = 0.0f; L.best.gprim = -1; L.best_S = 1.0f;
     L.cur = 0; L.sp = 0;
 }
 __device__ __forceinline__ void trav_push(const TreeView &tv, LaneTrav &L, int v) {
@@ -111,6 +114,12 @@ __device__ __forceinline__ int trav_pop(const TreeView &tv, LaneTrav &L) {
     L.sp--;
     if (L.sp < tv.cap) return tv.stack[L.sp * kBlock];
     return tv.spill[(uint32_t)(L.sp - tv.cap) * tv.spill_stride];
+}
+
+// the one barycentric division of a closest-hit query (dtrace.h tri_test: u = U * (1 / S))
+__device__ __forceinline__ void trav_finish(LaneTrav &L) {
+    const float rS = 1.0f / L.best_S;
+    L.best.u = L.best.u * rS; L.best.v = L.best.v * rS;
 }
 
 __device__ __forceinline__ void csw(float &ta, int &ca, float &tb, int &cb) {  // compare-exchange: nearer entry first
@@ -191,17 +200,17 @@ __device__ __forceinline__ void trav_leaf_step(const TreeView &tv, LaneTrav &L, 
         const int gprim = __float_as_int(p0.w), kind = __float_as_int(p1.w);
         if (!SPHERES || kind == 0) {
             const float v0[3] = {p0.x, p0.y, p0.z}, v1[3] = {p1.x, p1.y, p1.z}, v2[3] = {p2.x, p2.y, p2.z};
-            float t, u, v;
-            if (tri_test(L.ray, L.best.t, v0, v1, v2, t, u, v)) {
+            float t, U, V, S;
+            if (tri_test_raw(L.ray, L.best.t, v0, v1, v2, t, U, V, S)) {
                 if (ANY_HIT) { L.best.gprim = gprim; stop = true; }
-                else if (t < L.best.t || (t == L.best.t && (L.best.gprim < 0 || gprim < L.best.gprim))) { L.best.t = t; L.best.u = u; L.best.v = v; L.best.gprim = gprim; }
+                else if (t < L.best.t || (t == L.best.t && (L.best.gprim < 0 || gprim < L.best.gprim))) { L.best.t = t; L.best.u = U; L.best.v = V; L.best_S = S; L.best.gprim = gprim; }
             }
         } else {
             double td;
             if (sphere_test(L.ray, tv.spheres[__float_as_int(p2.w)], td)) {
                 const float tf = (float)td;
                 if (ANY_HIT) { L.best.gprim = gprim; stop = true; }
-                else if (tf < L.best.t || (tf == L.best.t && (L.best.gprim < 0 || gprim < L.best.gprim))) { L.best.t = tf; L.best.u = 0.0f; L.best.v = 0.0f; L.best.gprim = gprim; }
+                else if (tf < L.best.t || (tf == L.best.t && (L.best.gprim < 0 || gprim < L.best.gprim))) { L.best.t = tf; L.best.u = 0.0f; L.best.v = 0.0f; L.best_S = 1.0f; L.best.gprim = gprim; }
             }
         }
     }
@@ -309,6 +318,7 @@ __global__ void __launch_bounds__(kBlock, (RESIDENT && !SPHERES && !STATS) ? LJ_
             } else {
                 const uint32_t code = (uint32_t)vis | (uint32_t)(L.best.gprim + 1);
                 const bool hit = L.best.gprim >= 0;
+                trav_finish(L);
                 q.rh[path] = mk4(hit ? L.best.t : 0.0f, L.best.u, L.best.v, u2f(code));
                 busy = false;
             }
@@ -450,6 +460,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_rays(DScene sc, const RayIO *r
             while (L.cur >= 0 && L.cur != kDone) trav_node_step<false>(tv, L);
             if (L.cur < 0) trav_leaf_step<false, true>(tv, L, occ != nullptr);
         }
+        trav_finish(L);
         if (occ) occ[i] = L.best.gprim >= 0 ? 1 : 0;
         else {
             HitIO o; o.t = 0; o.u = 0; o.v = 0; o.shape_id = -1; o.prim_id = -1;
@@ -477,6 +488,7 @@ __global__ void __launch_bounds__(kBlock) k_aux(DScene sc, const uint32_t *pixel
             while (L.cur >= 0 && L.cur != kDone) trav_node_step<false>(tv, L);
             if (L.cur < 0) trav_leaf_step<false, true>(tv, L, false);
         }
+        trav_finish(L);
         const f3 c = aux_value(sc, integrator, org, dir, L.best.t, L.best.u, L.best.v, L.best.gprim);
         rgb[3ull * pixel] = c.x; rgb[3ull * pixel + 1] = c.y; rgb[3ull * pixel + 2] = c.z;
     }
