@@ -253,7 +253,11 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
         for (uint32_t l = 0; l < n_lanes; l++) {
             Lane &L = lanes[l];
             L.parity = 0; L.done = false; L.batch = 8;  // steps per host round trip; all per-step state lives on the device
+            // stagger: lane l starts when lane l-1 has generated its camera rays, so its shade launches fall on the other
+            // lane's extend launches (the two lanes have equal work per step, so the phase offset persists)
+            if (l > 0) HIP_CHECK(hipStreamWaitEvent(L.stream, ctx->ev_join, 0));
             ljd::launch_shade(ds, pass, L.q, L.dblocks, lane_blocks, seg, sc->scfg, L.work, L.lists[0], 0, ext_grid * 4u, L.stream);
+            if (l + 1 < n_lanes) HIP_CHECK(hipEventRecord(ctx->ev_join, L.stream));
         }
         // Round-robin over the lanes: look at a lane's block states only when its previous batch has drained, and give it
         // its next batch at once, so the other lane's kernels keep the GPU busy during this lane's host round trip.

@@ -3,6 +3,7 @@
 #include "flatten.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -190,7 +191,9 @@ FlatScene flatten_scene(const LjSceneDesc &d) {
 
     // ---- BVH (replaces rtcCommitScene)
     std::vector<int> order;
-    build_bvh(bprims, 4, 38, F.nodes, order, F.bvh_depth);
+    int max_leaf = 4;
+    if (const char *e = getenv("LJ_TUNE_MAX_LEAF")) max_leaf = std::min(8, std::max(1, atoi(e)));
+    build_bvh(bprims, max_leaf, 38, F.nodes, order, F.bvh_depth);
     F.leaf_prims.resize(gprims.size());
     for (size_t i = 0; i < order.size(); i++) F.leaf_prims[i] = gprims[order[i]];
 
