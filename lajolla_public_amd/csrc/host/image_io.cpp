@@ -5,8 +5,9 @@
 //   .pfm          portable float map (colour "PF" / grey "Pf"), bottom-up, endianness by the sign of the scale
 //   .jpg / .jpeg  baseline JPEG (jpeg_decode.cpp), then the LDR -> linear conversion stb's stbi_loadf applies:
 //                 (float) pow(v / 255.0f, 2.2f)  (stb_image.h:1553,1849) — what the reference's ImageTextures hold.
-// OpenEXR is not decoded yet: the one EXR the BASELINE scenes use (matpreview/envmap.exr) ships in this
-// repo as a PFM converted with the reference's own decoder (oracle/convert_assets.cpp); other formats fail loudly.
+//   .exr          single-part scan-line OpenEXR, HALF / FLOAT / UINT channels, NONE / ZIPS / ZIP / PIZ (exr_decode.cpp);
+//                 three channels = R, G, B; one channel = their mean (image.cpp:70-72)
+// Other formats fail loudly.
 #include "host_scene.h"
 #include <algorithm>
 #include <cmath>
@@ -17,6 +18,7 @@
 namespace lj {
 
 std::vector<uint8_t> decode_jpeg_rgb8(const std::vector<uint8_t> &file, int &width, int &height, const std::string &name);
+HostImage decode_exr_rgb(const std::vector<uint8_t> &file, const std::string &name);
 
 namespace {
 
@@ -67,6 +69,18 @@ HostImage convert_channels(const HostImage &src, int channels) {
 HostImage read_image(const std::string &filename, int channels) {
     std::string ext = ext_of(filename);
     if (ext == ".pfm") return convert_channels(read_pfm(filename), channels);
+    if (ext == ".exr") {
+        std::ifstream f(filename, std::ios::binary);
+        if (!f) throw LjError(LJ_ERR_IO, "cannot open image: " + filename);
+        std::vector<uint8_t> bytes((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+        HostImage rgb = decode_exr_rgb(bytes, filename);
+        if (channels != 1) return rgb;
+        HostImage g; g.width = rgb.width; g.height = rgb.height; g.channels = 1;
+        g.data.resize((size_t)rgb.width * rgb.height);
+        for (size_t i = 0; i < g.data.size(); i++)   // image.cpp:70-72, in the reference's double arithmetic
+            g.data[i] = (float)(((double)rgb.data[3 * i] + (double)rgb.data[3 * i + 1] + (double)rgb.data[3 * i + 2]) / 3);
+        return g;
+    }
     if (ext == ".jpg" || ext == ".jpeg") {
         std::ifstream f(filename, std::ios::binary);
         if (!f) throw LjError(LJ_ERR_IO, "cannot open image: " + filename);

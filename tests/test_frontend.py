@@ -110,10 +110,20 @@ def test_disney_bsdf_scene_matches_reference_parser():
     """Mitsuba .serialized v3 meshes (load_serialized.cpp:174-256), DisneyBSDF + checkerboard, rotated envmap."""
     hs, g = check_scene("disney_bsdf")
     assert hs.desc.n_triangles == 61600 and hs.desc.envmap_light_id == 0
-    im = hs.desc.images3[0]   # envmap level 0 (the repo ships the EXR converted to PFM by the reference's own decoder)
+    im = hs.desc.images3[0]   # envmap level 0: OpenEXR, HALF channels, PIZ compression (exr_decode.cpp)
     arr = np.ctypeslib.as_array(im.data, shape=(im.height, im.width, 3)).astype(np.float64)
     assert (im.width, im.height) == tuple(g["image3s"][0]["dims"][0])
     assert close(arr.sum(axis=(0, 1)), g["image3s"][0]["level_sums"][0], rel=1e-12)
+    # ... and texel for texel against the PFM the reference's own loader (tinyexr via imread3) wrote of the same file
+    # (oracle/convert_assets.cpp): HALF -> float is exact, so the two must be bit-identical
+    with open(os.path.join(ROOT, "scenes", "matpreview", "envmap.pfm"), "rb") as f:
+        assert f.readline().strip() == b"PF"
+        w, h = map(int, f.readline().split())
+        scale = float(f.readline())
+        ref = np.frombuffer(f.read(), dtype="<f4" if scale < 0 else ">f4").reshape(h, w, 3)[::-1]   # PFM is bottom-up
+    got = np.ctypeslib.as_array(im.data, shape=(im.height, im.width, 3))
+    assert (w, h) == (im.width, im.height)
+    assert np.array_equal(got.view(np.uint32), np.ascontiguousarray(ref, dtype=np.float32).view(np.uint32))
 
 
 def test_sponza_matches_reference_parser_and_jpeg_decoder():
