@@ -116,7 +116,7 @@ def test_disney_bsdf_scene_matches_reference_parser():
     assert close(arr.sum(axis=(0, 1)), g["image3s"][0]["level_sums"][0], rel=1e-12)
     # ... and texel for texel against the PFM the reference's own loader (tinyexr via imread3) wrote of the same file
     # (oracle/convert_assets.cpp): HALF -> float is exact, so the two must be bit-identical
-    with open(os.path.join(ROOT, "scenes", "matpreview", "envmap.pfm"), "rb") as f:
+    with open(os.path.join(ROOT, "tests", "golden", "matpreview_envmap_reference_decode.pfm"), "rb") as f:
         assert f.readline().strip() == b"PF"
         w, h = map(int, f.readline().split())
         scale = float(f.readline())
