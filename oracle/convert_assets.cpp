@@ -1,6 +1,6 @@
 // TEST/ASSET TOOL (authoring container only) — decodes scenes/matpreview/envmap.exr (512x256, HALF, PIZ) with the
-// reference's own imread3 (image.cpp:80-133 -> tinyexr) and writes the pixels as a PFM next to it.  The product's front
-// end does not decode OpenEXR yet; scenes/disney_bsdf_test/*.xml in this repo reference the .pfm.
+// reference's own imread3 (image.cpp:80-133 -> tinyexr) and writes the pixels as a PFM: the golden fixture
+// tests/golden/matpreview_envmap_reference_decode.pfm that the product's OpenEXR reader is held to, bit for bit.
 // Half -> float is exact, so the PFM holds bit-for-bit what the reference's TexturePool would hold at level 0.
 #include "image.h"
 #include <cstdio>
