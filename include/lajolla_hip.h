@@ -225,6 +225,13 @@ typedef struct LjSceneInfo {
 } LjSceneInfo;
 int lj_scene_info(const lj_scene *scene, LjSceneInfo *out);
 
+/* imwrite() (image.h:46, image.cpp:135-173), host only: writes a width x height RGB float image (row-major, y = 0 at the
+ * top) by extension — ".pfm": "PF", "<w> <h>", "-1", then the rows top to bottom as little-endian float (the
+ * reference's layout, image.cpp:141-149); ".exr": scan-line OpenEXR, HALF channels B, G, R (what the reference asks
+ * tinyexr for with "write as fp16", image.cpp:161).  The reference ignores other extensions; here they are
+ * LJ_ERR_UNSUPPORTED. */
+int lj_image_write(const char *filename, int32_t width, int32_t height, const float *rgb);
+
 #ifdef __cplusplus
 }
 #endif

@@ -101,6 +101,14 @@ def parse_scene(path):
     return HostScene(h)
 
 
+def write_image(path, rgb):
+    """imwrite() (image.cpp:135-173): `rgb` is (h, w, 3); .pfm in the reference's top-down layout, or .exr (HALF)."""
+    a = np.ascontiguousarray(rgb, dtype=np.float32)
+    if a.ndim != 3 or a.shape[2] != 3:
+        raise ValueError("write_image expects an (h, w, 3) array")
+    _check(load_library().lj_image_write(os.fsencode(path), a.shape[1], a.shape[0], a.ctypes.data_as(C.c_void_p)))
+
+
 class Context:
     """One HIP device + stream + workspace."""
 

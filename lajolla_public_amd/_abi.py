@@ -132,4 +132,5 @@ SYMBOLS = [
     ("lj_occluded", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     ("lj_get_stats", C.c_int, [C.c_void_p, C.POINTER(LjStats)]),
     ("lj_scene_info", C.c_int, [C.c_void_p, C.POINTER(LjSceneInfo)]),
+    ("lj_image_write", C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.c_void_p]),
 ]

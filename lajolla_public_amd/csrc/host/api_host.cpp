@@ -33,4 +33,11 @@ void lj_host_scene_free(lj_host_scene *hs) {
     delete hs;
 }
 
+int lj_image_write(const char *filename, int32_t width, int32_t height, const float *rgb) {
+    return lj::guard([&]() {
+        if (!filename || !rgb) throw lj::LjError(LJ_ERR_INVALID_ARG, "lj_image_write: null argument");
+        lj::write_image(filename, width, height, rgb);
+    });
+}
+
 } // extern "C"

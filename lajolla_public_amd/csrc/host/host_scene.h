@@ -51,5 +51,7 @@ LjShape load_serialized_mesh(HostScene &hs, const std::string &filename, int sha
 
 // image_io.cpp — imread3 / imread1 (image.cpp:28-133)
 HostImage read_image(const std::string &filename, int channels);
+// imwrite (image.cpp:135-173): .pfm (the reference's top-down layout) or .exr (HALF, scan-line)
+void write_image(const std::string &filename, int width, int height, const float *rgb);
 
 } // namespace lj

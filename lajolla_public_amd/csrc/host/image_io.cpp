@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <fstream>
 #include <sstream>
 
@@ -98,6 +99,81 @@ HostImage read_image(const std::string &filename, int channels) {
         return img;
     }
     throw LjError(LJ_ERR_UNSUPPORTED, "image format '" + ext + "' is not decoded by this build yet (SURVEY §8f-2): " + filename);
+}
+
+// ------------------------------------------------------------------ imwrite (image.cpp:135-173)
+namespace {
+
+uint16_t float_to_half(float f) {   // round to nearest even, overflow to infinity, subnormals kept
+    uint32_t x; memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    const int32_t e = (int32_t)((x >> 23) & 0xff) - 127 + 15;
+    uint32_t m = x & 0x7fffffu;
+    if (((x >> 23) & 0xff) == 0xff) return (uint16_t)(sign | 0x7c00u | (m ? 0x200u | (m >> 13) : 0));   // inf / NaN
+    if (e >= 31) return (uint16_t)(sign | 0x7c00u);
+    if (e <= 0) {
+        if (e < -10) return (uint16_t)sign;
+        m |= 0x800000u;
+        const int shift = 14 - e;   // 14..24
+        uint32_t h = m >> shift;
+        const uint32_t rem = m & ((1u << shift) - 1), halfway = 1u << (shift - 1);
+        if (rem > halfway || (rem == halfway && (h & 1))) h++;
+        return (uint16_t)(sign | h);
+    }
+    uint32_t h = ((uint32_t)e << 10) | (m >> 13);
+    const uint32_t rem = m & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1))) h++;   // a carry into the exponent is the right answer, up to inf
+    return (uint16_t)(sign | h);
+}
+
+} // namespace
+
+void write_image(const std::string &filename, int width, int height, const float *rgb) {
+    if (width <= 0 || height <= 0 || !rgb) throw LjError(LJ_ERR_INVALID_ARG, "write_image: empty image");
+    const std::string ext = ext_of(filename);
+    if (ext != ".pfm" && ext != ".exr") throw LjError(LJ_ERR_UNSUPPORTED, "images are written as .pfm or .exr: " + filename);
+    std::ofstream f(filename, std::ios::binary);
+    if (!f) throw LjError(LJ_ERR_IO, "cannot create image: " + filename);
+    const size_t n = (size_t)width * height;
+    if (ext == ".pfm") {
+        f << "PF\n" << width << " " << height << "\n-1\n";
+        f.write((const char *)rgb, (std::streamsize)(n * 3 * sizeof(float)));   // little-endian host, rows top to bottom
+    } else {
+        auto put32 = [&](uint32_t v) { const unsigned char b[4] = {(unsigned char)v, (unsigned char)(v >> 8), (unsigned char)(v >> 16), (unsigned char)(v >> 24)}; f.write((const char *)b, 4); };
+        auto put64 = [&](uint64_t v) { put32((uint32_t)v); put32((uint32_t)(v >> 32)); };
+        auto attr = [&](const char *name, const char *type, const std::string &value) {
+            f.write(name, (std::streamsize)strlen(name) + 1); f.write(type, (std::streamsize)strlen(type) + 1);
+            put32((uint32_t)value.size()); f.write(value.data(), (std::streamsize)value.size());
+        };
+        auto i32s = [](std::initializer_list<int32_t> v) { std::string s; for (int32_t x : v) { uint32_t u = (uint32_t)x; for (int k = 0; k < 4; k++) s.push_back((char)(u >> (8 * k))); } return s; };
+        auto f32s = [](std::initializer_list<float> v) { std::string s; for (float x : v) { uint32_t u; memcpy(&u, &x, 4); for (int k = 0; k < 4; k++) s.push_back((char)(u >> (8 * k))); } return s; };
+        std::ostringstream header;
+        put32(20000630u); put32(2u);
+        std::string chlist;
+        for (const char *c : {"B", "G", "R"}) { chlist += c; chlist.push_back('\0'); chlist += i32s({1}); chlist += std::string(4, '\0'); chlist += i32s({1, 1}); }
+        chlist.push_back('\0');
+        attr("channels", "chlist", chlist);
+        attr("compression", "compression", std::string(1, '\0'));
+        attr("dataWindow", "box2i", i32s({0, 0, width - 1, height - 1}));
+        attr("displayWindow", "box2i", i32s({0, 0, width - 1, height - 1}));
+        attr("lineOrder", "lineOrder", std::string(1, '\0'));
+        attr("pixelAspectRatio", "float", f32s({1.0f}));
+        attr("screenWindowCenter", "v2f", f32s({0.0f, 0.0f}));
+        attr("screenWindowWidth", "float", f32s({1.0f}));
+        f.put('\0');
+        const uint64_t line_bytes = (uint64_t)width * 3 * 2, table = (uint64_t)f.tellp() + (uint64_t)height * 8;
+        for (int y = 0; y < height; y++) put64(table + (uint64_t)y * (8 + line_bytes));
+        std::vector<uint16_t> line((size_t)width * 3);
+        for (int y = 0; y < height; y++) {
+            put32((uint32_t)y); put32((uint32_t)line_bytes);
+            const float *row = rgb + (size_t)y * width * 3;
+            for (int x = 0; x < width; x++) {   // channel rows in alphabetical order: B, G, R
+                line[x] = float_to_half(row[3 * x + 2]); line[width + x] = float_to_half(row[3 * x + 1]); line[2 * (size_t)width + x] = float_to_half(row[3 * x]);
+            }
+            f.write((const char *)line.data(), (std::streamsize)line_bytes);
+        }
+    }
+    if (!f) throw LjError(LJ_ERR_IO, "write failed: " + filename);
 }
 
 } // namespace lj

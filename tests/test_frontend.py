@@ -205,3 +205,32 @@ def test_obj_loader_quads_and_synthesised_normals(tmp_path):
     assert np.allclose(hs.uvs(), [[0, 1], [1, 1], [1, 0], [0, 0.75]])
     assert np.allclose(hs.normals(), [[0, 0, 1]] * 4)
     assert hs.desc.shapes[0].has_normals == 1 and hs.desc.shapes[0].has_uvs == 1
+
+
+def test_image_writers_round_trip(tmp_path):
+    """imwrite (image.cpp:135-173).  PFM: the reference's header and top-down float rows, byte for byte.  EXR: HALF
+    scan-line file that our own reader (and any OpenEXR reader) takes back; values are the nearest halfs."""
+    rng = np.random.default_rng(3)
+    img = (rng.random((37, 53, 3)) * 4).astype(np.float32)
+    img[0, 0] = [0.0, 1e-7, 70000.0]   # zero, a half subnormal, overflow to +inf
+    pfm = tmp_path / "out.pfm"
+    lj.write_image(str(pfm), img)
+    raw = pfm.read_bytes()
+    head = b"PF\n53 37\n-1\n"
+    assert raw[:len(head)] == head and raw[len(head):] == img.tobytes()
+    exr = tmp_path / "env.exr"
+    lj.write_image(str(exr), img)
+    scene = tmp_path / "s.xml"
+    scene.write_text(f"""<scene version="0.6.0"><integrator type="path"/><sensor type="perspective"><film type="hdrfilm">
+        <integer name="width" value="8"/><integer name="height" value="8"/></film></sensor>
+        <emitter type="envmap"><string name="filename" value="{exr}"/></emitter>
+        <shape type="sphere"><bsdf type="diffuse"/></shape></scene>""")
+    hs = lj.parse_scene(str(scene))
+    im = hs.desc.images3[0]
+    got = np.ctypeslib.as_array(im.data, shape=(im.height, im.width, 3))
+    assert (im.width, im.height) == (53, 37)
+    with np.errstate(over="ignore"):
+        assert np.array_equal(got, img.astype(np.float16).astype(np.float32))
+    with pytest.raises(lj.LajollaError) as e:
+        lj.write_image(str(tmp_path / "out.png"), img)
+    assert e.value.code == _abi.LJ_ERR_UNSUPPORTED
