@@ -125,6 +125,28 @@ typedef struct LjCamera {
     double filter_param;  /* Box::width / Tent::width / Gaussian::stddev */
 } LjCamera;
 
+/* VolumeSpectrum (volume.h:13-30): a constant, or a grid of RGB values interpolated trilinearly inside [p_min, p_max]. */
+typedef enum LjVolumeKind { LJ_VOLUME_CONSTANT = 0, LJ_VOLUME_GRID = 1 } LjVolumeKind;
+typedef struct LjVolume {
+    int32_t kind;               /* LJ_VOLUME_* */
+    int32_t resolution[3];      /* grid: x, y, z */
+    double value[3];            /* constant (the medium's scale already applied, volume.h:105-107) */
+    double p_min[3], p_max[3], max_data[3];
+    double scale;               /* GridVolume::scale (set_scale, volume.h:109-111) */
+    const float *data;          /* grid: 3 floats per voxel, x fastest; the file's float32 values (volume.cpp:62-98) */
+} LjVolume;
+
+/* Medium (medium.h:10-21) with its PhaseFunction (phase_function.h:10-17). */
+typedef enum LjMediumKind { LJ_MEDIUM_HOMOGENEOUS = 0, LJ_MEDIUM_HETEROGENEOUS = 1 } LjMediumKind;
+typedef enum LjPhaseKind { LJ_PHASE_ISOTROPIC = 0, LJ_PHASE_HG = 1 } LjPhaseKind;
+typedef struct LjMedium {
+    int32_t kind;               /* LJ_MEDIUM_* */
+    int32_t phase_kind;         /* LJ_PHASE_* */
+    double g;                   /* HenyeyGreenstein::g */
+    double sigma_a[3], sigma_s[3];   /* homogeneous */
+    LjVolume albedo, density;        /* heterogeneous */
+} LjMedium;
+
 typedef struct LjRenderOptions {
     int32_t integrator;  /* LJ_INTEGRATOR_* */
     int32_t samples_per_pixel, max_depth, rr_depth, vol_path_version, max_null_collisions;
@@ -148,6 +170,8 @@ typedef struct LjSceneDesc {
     const double *uvs;        /* 2 per vertex; garbage where !has_uvs */
     const int32_t *indices;   /* 3 per triangle, mesh-local */
     const char *output_filename;
+    int32_t n_media, _pad_media;
+    const LjMedium *media;    /* Scene::media (scene.h:66); referenced by LjCamera::medium_id and LjShape::*_medium_id */
 } LjSceneDesc;
 
 /* ---------------------------------------------------------------- front end (host only)

@@ -71,6 +71,22 @@ class LjRenderOptions(C.Structure):
                 ("rr_depth", C.c_int32), ("vol_path_version", C.c_int32), ("max_null_collisions", C.c_int32)]
 
 
+LJ_VOLUME_CONSTANT, LJ_VOLUME_GRID = 0, 1
+LJ_MEDIUM_HOMOGENEOUS, LJ_MEDIUM_HETEROGENEOUS = 0, 1
+LJ_PHASE_ISOTROPIC, LJ_PHASE_HG = 0, 1
+
+
+class LjVolume(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("resolution", C.c_int32 * 3), ("value", C.c_double * 3),
+                ("p_min", C.c_double * 3), ("p_max", C.c_double * 3), ("max_data", C.c_double * 3),
+                ("scale", C.c_double), ("data", C.POINTER(C.c_float))]
+
+
+class LjMedium(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("phase_kind", C.c_int32), ("g", C.c_double),
+                ("sigma_a", C.c_double * 3), ("sigma_s", C.c_double * 3), ("albedo", LjVolume), ("density", LjVolume)]
+
+
 class LjSceneDesc(C.Structure):
     _fields_ = [("camera", LjCamera), ("options", LjRenderOptions),
                 ("n_shapes", C.c_int32), ("n_materials", C.c_int32), ("n_lights", C.c_int32),
@@ -80,7 +96,8 @@ class LjSceneDesc(C.Structure):
                 ("n_vertices", C.c_int64), ("n_triangles", C.c_int64),
                 ("positions", C.POINTER(C.c_double)), ("normals", C.POINTER(C.c_double)),
                 ("uvs", C.POINTER(C.c_double)), ("indices", C.POINTER(C.c_int32)),
-                ("output_filename", C.c_char_p)]
+                ("output_filename", C.c_char_p),
+                ("n_media", C.c_int32), ("_pad_media", C.c_int32), ("media", C.POINTER(LjMedium))]
 
 
 class LjRenderArgs(C.Structure):

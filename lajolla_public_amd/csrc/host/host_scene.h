@@ -26,6 +26,9 @@ struct HostScene {
     std::vector<LjShape> shapes;
     std::vector<LjMaterial> materials;
     std::vector<LjLight> lights;
+    std::vector<LjMedium> media;                       // LjVolume::data point into volume_data (set by finalize)
+    std::vector<std::vector<float>> volume_data;       // one entry per grid volume, 3 floats per voxel
+    std::vector<std::pair<int, int>> volume_owner;     // (medium index, 0 = albedo / 1 = density) of each volume_data entry
     std::vector<HostImage> images3, images1;
     std::map<std::string, int> image3s_map, image1s_map;  // TexturePool maps (texture.h:13-19)
     std::vector<double> positions, normals, uvs;
@@ -48,6 +51,9 @@ HostScene *parse_scene_xml(const std::string &path);
 // mesh_io.cpp — both append one TriangleMesh to the pools and return its LjShape (ids unset)
 LjShape load_obj_mesh(HostScene &hs, const std::string &filename, const M4 &to_world);
 LjShape load_serialized_mesh(HostScene &hs, const std::string &filename, int shape_index, const M4 &to_world);
+
+// mesh_io.cpp — load_volume_from_file<Spectrum> (volume.cpp:6-104): Mitsuba gridvolume, float32, 1 or 3 channels
+void load_grid_volume(const std::string &filename, LjVolume &v, std::vector<float> &data);
 
 // image_io.cpp — imread3 / imread1 (image.cpp:28-133)
 HostImage read_image(const std::string &filename, int channels);

@@ -218,4 +218,38 @@ LjShape load_serialized_mesh(HostScene &hs, const std::string &filename, int sha
     return append_mesh(hs, pos, nor, uv, idx);
 }
 
+// load_volume_from_file<Spectrum> (volume.cpp:6-104): Mitsuba's gridvolume file — "VOL", version 3, type 1 (float32),
+// resolution, channel count (1 or 3), bounding box as six floats, then the voxels, x fastest.  A one-channel file is
+// replicated to three (volume.cpp:84-87); max_data is the per-channel maximum, starting from zero.
+void load_grid_volume(const std::string &filename, LjVolume &v, std::vector<float> &data) {
+    std::ifstream f(filename, std::ios::binary);
+    if (!f) throw LjError(LJ_ERR_IO, "cannot open volume: " + filename);
+    char header[4];
+    f.read(header, 4);
+    if (!f || header[0] != 'V' || header[1] != 'O' || header[2] != 'L' || header[3] != 3)
+        throw LjError(LJ_ERR_PARSE, "Error loading volume from a file (incorrect header). Filename:" + filename);
+    int32_t type = 0, res[3] = {0, 0, 0}, channels = 0;
+    f.read((char *)&type, 4);
+    if (type != 1) throw LjError(LJ_ERR_UNSUPPORTED, "Unsupported volume format (only support Float32). Filename:" + filename);
+    f.read((char *)res, 12); f.read((char *)&channels, 4);
+    if (channels != 1 && channels != 3) throw LjError(LJ_ERR_UNSUPPORTED, "Unsupported volume format (wrong number of channels). Filename:" + filename);
+    float box[6];
+    f.read((char *)box, 24);
+    if (!f || res[0] <= 0 || res[1] <= 0 || res[2] <= 0) throw LjError(LJ_ERR_PARSE, "malformed volume header: " + filename);
+    const size_t n = (size_t)res[0] * res[1] * res[2];
+    std::vector<float> raw(n * channels, 0.0f);
+    f.read((char *)raw.data(), (std::streamsize)(raw.size() * 4));   // a short file leaves zeros, as the reference's read does
+    v = LjVolume{};
+    v.kind = LJ_VOLUME_GRID; v.scale = 1;
+    for (int k = 0; k < 3; k++) { v.resolution[k] = res[k]; v.p_min[k] = box[k]; v.p_max[k] = box[3 + k]; v.max_data[k] = 0; }
+    data.resize(n * 3);
+    for (size_t i = 0; i < n; i++)
+        for (int k = 0; k < 3; k++) {
+            const float x = channels == 1 ? raw[i] : raw[3 * i + k];
+            data[3 * i + k] = x;
+            if ((double)x > v.max_data[k]) v.max_data[k] = x;
+        }
+    v.data = data.data();
+}
+
 } // namespace lj

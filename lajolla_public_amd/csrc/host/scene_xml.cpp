@@ -180,6 +180,7 @@ struct Parser {
     std::string base_dir;
     std::map<std::string, int> material_map;
     std::map<std::string, ParsedTexture> texture_map;
+    std::map<std::string, int> medium_map;
 
     // TexturePool::insert_image3 / insert_image1 (texture.h:21-63): keyed by texture name, first insert wins.
     int insert_image3(const std::string &name, const std::string &file) {
@@ -341,7 +342,7 @@ struct Parser {
     }
 
     int parse_sensor(const XmlNode &n) {  // parse_scene.cpp:459-556; returns the sampler's sampleCount
-        double fov = 45.0; M4 to_world = M4::identity(); Film film; int sample_count = 4;
+        double fov = 45.0; M4 to_world = M4::identity(); Film film; int sample_count = 4; int sensor_medium_id = -1;
         enum { X, Y, DIAGONAL, SMALLER, LARGER } axis = X;
         const std::string &type = n.attr("type");
         if (type != "perspective") parse_error("Unsupported sensor: " + type);
@@ -365,7 +366,17 @@ struct Parser {
                     fprintf(stderr, "Warning: the renderer currently only supports independent samplers.\n");
                 for (auto &g : c.children) if (g->attr("name") == "sampleCount") sample_count = stoi_i(g->attr("value"));
             }
-            // <ref>/<medium> children: participating media are outside the accelerated path
+            else if (c.name == "ref") {  // a reference to a medium (parse_scene.cpp:517-527)
+                if (!c.has("id")) parse_error("Medium reference not specified.");
+                auto mt = medium_map.find(c.attr("id"));
+                if (mt == medium_map.end()) parse_error("Medium reference " + c.attr("id") + " not found.");
+                sensor_medium_id = mt->second;
+            } else if (c.name == "medium") {
+                LjMedium m; std::string mname = parse_medium(c, m);
+                if (!mname.empty()) medium_map[mname] = (int)hs.media.size();
+                sensor_medium_id = (int)hs.media.size();
+                hs.media.push_back(m);
+            }
         }
         int width = film.width, height = film.height;
         if (axis == Y || (axis == SMALLER && height < width) || (axis == LARGER && width < height)) {
@@ -378,6 +389,7 @@ struct Parser {
             fov = degrees(2 * std::atan(wd / 2));
         }
         hs.camera = make_camera(to_world, fov, width, height, film.filter_kind, film.filter_param);
+        hs.camera.medium_id = sensor_medium_id;
         hs.output_filename = film.filename;
         return sample_count;
     }
@@ -428,14 +440,83 @@ struct Parser {
         return true;
     }
 
+    // parse_volume_spectrum (parse_scene.cpp:359-386)
+    LjVolume parse_volume(const XmlNode &n, int medium_index, int which) {
+        LjVolume v{};
+        const std::string &type = n.attr("type");
+        if (type == "constvolume") {
+            v.kind = LJ_VOLUME_CONSTANT;
+            for (auto &cp : n.children) if (cp->attr("name") == "value") { V3 c = parse_color(*cp); v.value[0] = c.x; v.value[1] = c.y; v.value[2] = c.z; }
+            v.scale = 1;
+        } else if (type == "gridvolume") {
+            std::string filename;
+            for (auto &cp : n.children) if (cp->attr("name") == "filename") filename = cp->attr("value");
+            if (filename.empty()) parse_error("Empty filename for a gridvolume.");
+            hs.volume_data.emplace_back();
+            hs.volume_owner.emplace_back(medium_index, which);
+            load_grid_volume(join_path(base_dir, filename), v, hs.volume_data.back());
+        } else parse_error("Unknown volume type:" + type);
+        return v;
+    }
+
+    // parse_medium (parse_scene.cpp:407-457) with parse_phase_function (:388-405); returns the medium's id attribute
+    std::string parse_medium(const XmlNode &n, LjMedium &m) {
+        m = LjMedium{};
+        m.phase_kind = LJ_PHASE_ISOTROPIC;
+        auto parse_phase = [&](const XmlNode &c) {
+            const std::string &pt = c.attr("type");
+            if (pt == "isotropic") { m.phase_kind = LJ_PHASE_ISOTROPIC; m.g = 0; }
+            else if (pt == "hg") {
+                m.phase_kind = LJ_PHASE_HG; m.g = 0;
+                for (auto &g : c.children) if (g->attr("name") == "g") m.g = stof_d(g->attr("value"));
+            } else parse_error("Unrecognized phase function:" + pt);
+        };
+        const std::string &type = n.attr("type");
+        const int index = (int)hs.media.size();
+        if (type == "homogeneous") {
+            m.kind = LJ_MEDIUM_HOMOGENEOUS;
+            V3 sa{0.5, 0.5, 0.5}, ss{0.5, 0.5, 0.5}; double scl = 1;
+            for (auto &cp : n.children) {
+                const XmlNode &c = *cp; const std::string &name = c.attr("name");
+                if (name == "sigmaA") sa = parse_color(c);
+                else if (name == "sigmaS") ss = parse_color(c);
+                else if (name == "scale") scl = stof_d(c.attr("value"));
+                else if (c.name == "phase") parse_phase(c);
+            }
+            sa = sa * scl; ss = ss * scl;
+            m.sigma_a[0] = sa.x; m.sigma_a[1] = sa.y; m.sigma_a[2] = sa.z; m.sigma_s[0] = ss.x; m.sigma_s[1] = ss.y; m.sigma_s[2] = ss.z;
+        } else if (type == "heterogeneous") {
+            m.kind = LJ_MEDIUM_HETEROGENEOUS;
+            m.albedo.kind = LJ_VOLUME_CONSTANT; m.albedo.value[0] = m.albedo.value[1] = m.albedo.value[2] = 1; m.albedo.scale = 1;
+            m.density = m.albedo;
+            double scl = 1;
+            for (auto &cp : n.children) {
+                const XmlNode &c = *cp; const std::string &name = c.attr("name");
+                if (name == "albedo") m.albedo = parse_volume(c, index, 0);
+                else if (name == "density") m.density = parse_volume(c, index, 1);
+                else if (name == "scale") scl = stof_d(c.attr("value"));
+                else if (c.name == "phase") parse_phase(c);
+            }
+            // "scale only applies to density" (parse_scene.cpp:449-450; set_scale, volume.h:100-111)
+            if (m.density.kind == LJ_VOLUME_CONSTANT) for (int k = 0; k < 3; k++) m.density.value[k] *= scl;
+            else m.density.scale = scl;
+        } else parse_error("Unknown medium type:" + type);
+        return n.has("id") ? n.attr("id") : std::string();
+    }
+
     void parse_shape(const XmlNode &n) {  // parse_scene.cpp:811-970
-        int material_id = -1;
+        int material_id = -1, interior_medium_id = -1, exterior_medium_id = -1;
         for (auto &cp : n.children) {
             const XmlNode &c = *cp;
             if (c.name == "ref") {
                 const std::string &nv = c.attr("name");
                 if (!c.has("id")) parse_error("Material/medium reference id not specified.");
-                if (nv == "interior" || nv == "exterior") continue;  // media: outside the accelerated path
+                if (nv == "interior" || nv == "exterior") {
+                    auto mt = medium_map.find(c.attr("id"));
+                    if (mt == medium_map.end()) parse_error("Medium reference " + c.attr("id") + " not found.");
+                    (nv == "interior" ? interior_medium_id : exterior_medium_id) = mt->second;
+                    continue;
+                }
                 auto it = material_map.find(c.attr("id"));
                 if (it == material_map.end()) parse_error("Material reference " + c.attr("id") + " not found.");
                 material_id = it->second;
@@ -445,6 +526,14 @@ struct Parser {
                 if (!mname.empty()) material_map[mname] = (int)hs.materials.size();
                 material_id = (int)hs.materials.size();
                 hs.materials.push_back(m);
+            } else if (c.name == "medium") {
+                LjMedium m; std::string mname = parse_medium(c, m);
+                if (!mname.empty()) medium_map[mname] = (int)hs.media.size();
+                const std::string &nv = c.attr("name");
+                if (nv == "interior") interior_medium_id = (int)hs.media.size();
+                else if (nv == "exterior") exterior_medium_id = (int)hs.media.size();
+                else parse_error("Unrecognized medium name: " + nv);
+                hs.media.push_back(m);
             }
         }
         const std::string &type = n.attr("type");
@@ -476,7 +565,7 @@ struct Parser {
             }
         } else parse_error("Unknown shape:" + type);
         shape.material_id = material_id; shape.area_light_id = -1;
-        shape.interior_medium_id = -1; shape.exterior_medium_id = -1;
+        shape.interior_medium_id = interior_medium_id; shape.exterior_medium_id = exterior_medium_id;
         for (auto &cp : n.children) {
             const XmlNode &c = *cp;
             if (c.name != "emitter") continue;
@@ -554,7 +643,11 @@ struct Parser {
                 hs.lights.push_back(l);
                 hs.envmap_light_id = (int)hs.lights.size() - 1;
             }
-            // <medium>: participating media are outside the accelerated path
+            else if (c.name == "medium") {  // parse_scene.cpp:1111-1119: only named top-level media are kept
+                LjMedium m; std::string mname = parse_medium(c, m);
+                if (!mname.empty()) { medium_map[mname] = (int)hs.media.size(); hs.media.push_back(m); }
+                else { while (!hs.volume_owner.empty() && hs.volume_owner.back().first == (int)hs.media.size()) { hs.volume_owner.pop_back(); hs.volume_data.pop_back(); } }
+            }
         }
     }
 };
@@ -571,7 +664,7 @@ HostScene *parse_scene_xml(const std::string &path) {
     catch (const std::runtime_error &e) { throw LjError(LJ_ERR_PARSE, std::string(e.what()) + " in " + path); }
     if (doc->name != "scene") throw LjError(LJ_ERR_PARSE, "root element is <" + doc->name + ">, expected <scene>");
     auto hs = std::make_unique<HostScene>();
-    Parser p{*hs, dirname_of(path), {}, {}};
+    Parser p{*hs, dirname_of(path), {}, {}, {}};
     p.parse_root(*doc);
     hs->finalize();
     return hs.release();
@@ -590,6 +683,11 @@ void HostScene::finalize() {
     desc.n_vertices = (int64_t)positions.size() / 3; desc.n_triangles = (int64_t)indices.size() / 3;
     desc.positions = positions.data(); desc.normals = normals.data(); desc.uvs = uvs.data(); desc.indices = indices.data();
     desc.output_filename = output_filename.c_str();
+    for (size_t i = 0; i < volume_data.size(); i++) {
+        LjMedium &m = media[volume_owner[i].first];
+        (volume_owner[i].second == 0 ? m.albedo : m.density).data = volume_data[i].data();
+    }
+    desc.n_media = (int)media.size(); desc.media = media.data();
 }
 
 HostScene *host_scene_from_desc(const LjSceneDesc &d) {
@@ -613,6 +711,17 @@ HostScene *host_scene_from_desc(const LjSceneDesc &d) {
     hs->indices.assign(d.indices, d.indices + d.n_triangles * 3);
     hs->envmap_light_id = d.envmap_light_id;
     if (d.output_filename) hs->output_filename = d.output_filename;
+    for (int i = 0; i < d.n_media; i++) {
+        hs->media.push_back(d.media[i]);
+        LjVolume *vols[2] = {&hs->media.back().albedo, &hs->media.back().density};
+        for (int w = 0; w < 2; w++) {
+            LjVolume &v = *vols[w];
+            if (d.media[i].kind != LJ_MEDIUM_HETEROGENEOUS || v.kind != LJ_VOLUME_GRID) { v.data = nullptr; continue; }
+            const size_t n = (size_t)v.resolution[0] * v.resolution[1] * v.resolution[2] * 3;
+            hs->volume_data.emplace_back(v.data, v.data + n);
+            hs->volume_owner.emplace_back(i, w);
+        }
+    }
     hs->finalize();
     return hs.release();
 }

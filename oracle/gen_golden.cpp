@@ -18,6 +18,9 @@
 //   * PathVertex fill  (intersection.cpp:38-62, given (shape, prim, u, v, t) instead of an Embree hit)
 // Each is marked GLUE below.
 #include "parse_scene.h"
+#include "medium.h"
+#include "phase_function.h"
+#include "volume.h"
 #include "parse_obj.h"
 #include "load_serialized.h"
 #include "transform.h"
@@ -46,6 +49,7 @@ Shape parse_shape(pugi::xml_node node, std::vector<Material> &materials,
     TexturePool &texture_pool, std::vector<Medium> &media, std::map<std::string, int> &medium_map,
     std::vector<Light> &lights, const std::vector<Shape> &shapes);
 ParsedTexture parse_texture(pugi::xml_node node);
+std::tuple<std::string, Medium> parse_medium(pugi::xml_node node);            // parse_scene.cpp:407
 Matrix4x4 parse_transform(pugi::xml_node node);
 Spectrum parse_color(pugi::xml_node node);
 
@@ -142,6 +146,10 @@ static void parse_with_reference(const fs::path &xml, Parsed &P) {
                 P.lights.push_back(Envmap{t, to_world, inverse(to_world), scale});
                 P.envmap_light_id = (int)P.lights.size() - 1;
             }
+        } else if (name == "medium") {  // parse_scene.cpp:1111-1119
+            std::string medium_name; Medium m;
+            std::tie(medium_name, m) = parse_medium(child);
+            if (!medium_name.empty()) { medium_map[medium_name] = P.media.size(); P.media.push_back(m); }
         }
     }
     fs::current_path(old_path);
@@ -628,6 +636,94 @@ static void gen_materials(const std::string &outdir) {
     j.eobj();
 }
 
+// ---------------------------------------------------------------- participating media
+static void dump_volume(J &j, const VolumeSpectrum &v) {
+    j.obj();
+    if (auto *c = std::get_if<ConstantVolume<Spectrum>>(&v)) { j.ks("kind", "constant"); j.kv3("value", c->value); }
+    else {
+        const auto &g = std::get<GridVolume<Spectrum>>(v);
+        j.ks("kind", "grid");
+        j.key("resolution"); j.arr(); j.inum(g.resolution.x); j.inum(g.resolution.y); j.inum(g.resolution.z); j.earr();
+        j.kv3("p_min", g.p_min); j.kv3("p_max", g.p_max); j.kv3("max_data", g.max_data); j.kv("scale", g.scale);
+        Vector3 sum{0, 0, 0}; for (auto &d : g.data) sum += d;
+        j.kv3("data_sum", sum);
+        j.key("samples"); j.arr();
+        const size_t st = std::max<size_t>(1, g.data.size() / 17);
+        for (size_t i = 0; i < g.data.size(); i += st) j.v3(g.data[i]);
+        j.earr();
+    }
+    j.eobj();
+}
+static void gen_media(const std::string &outdir, const fs::path &ref) {
+    J j(outdir + "/media.json");
+    j.obj();
+    j.ks("generator", "oracle/gen_golden.cpp on the reference's parse_medium / get_majorant / get_sigma_* / phase function code");
+    g_rng = init_pcg32(11);
+    // phase functions (phase_functions/*.inl)
+    j.key("phase"); j.arr();
+    const Real gs[] = {Real(-1), Real(-0.7), Real(0.0005), Real(0.3), Real(0.9)};   // -1: isotropic
+    for (Real g : gs) {
+        PhaseFunction pf = g == Real(-1) ? PhaseFunction{IsotropicPhase{}} : PhaseFunction{HenyeyGreenstein{g}};
+        j.obj(); j.kv("g", g); j.ki("isotropic", g == Real(-1) ? 1 : 0);
+        j.key("cases"); j.arr();
+        for (int i = 0; i < 24; i++) {
+            Vector3 din = rnd_dir(), dout = rnd_dir(); Vector2 uv{rnd(), rnd()};
+            j.obj(); j.kv3("dir_in", din); j.kv3("dir_out", dout); j.kv2("uv", uv);
+            j.kv3("eval", eval(pf, din, dout)); j.kv("pdf", pdf_sample_phase(pf, din, dout));
+            auto smp = sample_phase_function(pf, din, uv);
+            j.kv3("sample", *smp);
+            j.eobj();
+        }
+        j.earr(); j.eobj();
+    }
+    j.earr();
+    // scenes: media as parsed + known answers of the medium queries
+    j.key("scenes"); j.obj();
+    for (const char *name : {"hetvol", "hetvol_colored", "vol_cbox_teapot", "volpath_test6", "volpath_test5", "volpath_test1"}) {
+        Parsed P; parse_with_reference(ref / "scenes/volpath_test" / (std::string(name) + ".xml"), P);
+        j.key(name); j.obj();
+        j.ki("camera_medium_id", P.camera.medium_id);
+        j.ki("integrator", (int)P.options.integrator); j.ki("vol_path_version", P.options.vol_path_version);
+        j.ki("max_null_collisions", P.options.max_null_collisions); j.ki("max_depth", P.options.max_depth); j.ki("rr_depth", P.options.rr_depth);
+        j.key("shape_media"); j.arr();
+        for (auto &sh : P.shapes) { j.arr(); j.inum(get_material_id(sh)); j.inum(get_interior_medium_id(sh)); j.inum(get_exterior_medium_id(sh)); j.earr(); }
+        j.earr();
+        j.key("media"); j.arr();
+        for (auto &m : P.media) {
+            j.obj();
+            PhaseFunction pf = get_phase_function(m);
+            if (auto *hg = std::get_if<HenyeyGreenstein>(&pf)) { j.ks("phase", "hg"); j.kv("g", hg->g); } else { j.ks("phase", "isotropic"); j.kv("g", 0); }
+            Vector3 lo{-1, -1, -1}, hi{1, 1, 1};
+            if (auto *h = std::get_if<HomogeneousMedium>(&m)) { j.ks("kind", "homogeneous"); j.kv3("sigma_a", h->sigma_a); j.kv3("sigma_s", h->sigma_s); }
+            else {
+                const auto &h2 = std::get<HeterogeneousMedium>(m);
+                j.ks("kind", "heterogeneous");
+                j.key("albedo"); dump_volume(j, h2.albedo); j.key("density"); dump_volume(j, h2.density);
+                if (auto *g = std::get_if<GridVolume<Spectrum>>(&h2.density)) { lo = g->p_min; hi = g->p_max; }
+            }
+            // queries: points in and a little around the volume's box; rays towards and past it
+            j.key("points"); j.arr();
+            for (int i = 0; i < 40; i++) {
+                Vector3 p{lo.x + (hi.x - lo.x) * (rnd() * Real(1.2) - Real(0.1)), lo.y + (hi.y - lo.y) * (rnd() * Real(1.2) - Real(0.1)), lo.z + (hi.z - lo.z) * (rnd() * Real(1.2) - Real(0.1))};
+                j.obj(); j.kv3("p", p); j.kv3("sigma_s", get_sigma_s(m, p)); j.kv3("sigma_a", get_sigma_a(m, p)); j.eobj();
+            }
+            j.earr();
+            j.key("rays"); j.arr();
+            for (int i = 0; i < 24; i++) {
+                Vector3 org{lo.x + (hi.x - lo.x) * (rnd() * 3 - 1), lo.y + (hi.y - lo.y) * (rnd() * 3 - 1), lo.z + (hi.z - lo.z) * (rnd() * 3 - 1)};
+                Ray ray{org, rnd_dir(), Real(0), i % 3 == 0 ? (hi.x - lo.x) * rnd() : infinity<Real>()};
+                j.obj(); j.kv3("org", ray.org); j.kv3("dir", ray.dir); j.kv("tfar", ray.tfar); j.kv3("majorant", get_majorant(m, ray)); j.eobj();
+            }
+            j.earr();
+            j.eobj();
+        }
+        j.earr();
+        j.eobj();
+    }
+    j.eobj();
+    j.eobj();
+}
+
 int main(int argc, char **argv) {
     if (argc < 3) { fprintf(stderr, "usage: gen_golden <reference_root> <outdir>\n"); return 1; }
     fs::path ref = fs::absolute(argv[1]); std::string out = fs::absolute(argv[2]).string();
@@ -637,6 +733,7 @@ int main(int argc, char **argv) {
     gen_scene(out, "veach_mi", ref / "scenes/veach_mi/mi.xml", true);
     gen_scene(out, "disney_bsdf", ref / "scenes/disney_bsdf_test/disney_bsdf.xml", false);
     gen_scene(out, "sponza", ref / "scenes/sponza/sponza.xml", false);
+    gen_media(out, ref);
     // _exit: static destructors of the leaked fake Scenes must never run (they would call into Embree).
     fflush(nullptr); _exit(0);
 }

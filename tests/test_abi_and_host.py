@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_sizes_match_the_header(tmp_path):
     """Compile a tiny C program against the header and compare sizeof() with the ctypes mirror."""
-    names = ["LjTexture", "LjMaterial", "LjShape", "LjLight", "LjImage", "LjCamera", "LjRenderOptions", "LjSceneDesc", "LjRenderArgs",
+    names = ["LjTexture", "LjMaterial", "LjShape", "LjLight", "LjImage", "LjCamera", "LjVolume", "LjMedium", "LjRenderOptions", "LjSceneDesc", "LjRenderArgs",
              "LjRay", "LjHit", "LjStats", "LjSceneInfo"]
     src = tmp_path / "sz.c"
     src.write_text('#include <stdio.h>\n#include "lajolla_hip.h"\nint main(){' + "".join(f'printf("%zu\\n", sizeof({n}));' for n in names) + "return 0;}")

@@ -234,3 +234,36 @@ def test_image_writers_round_trip(tmp_path):
     with pytest.raises(lj.LajollaError) as e:
         lj.write_image(str(tmp_path / "out.png"), img)
     assert e.value.code == _abi.LJ_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("name", ["hetvol", "hetvol_colored", "vol_cbox_teapot", "volpath_test6", "volpath_test5", "volpath_test1"])
+def test_media_match_reference_parser(name):
+    """parse_medium / parse_phase_function / parse_volume_spectrum / load_volume (parse_scene.cpp:359-457, volume.cpp:6-104):
+    media, their order, the shapes' interior / exterior references and the grid volumes' voxels, against the reference's
+    own parser (tests/golden/media.json)."""
+    g = golden("media")["scenes"][name]
+    hs = lj.parse_scene(os.path.join(ROOT, "scenes", "volpath_test", name + ".xml"))
+    d = hs.desc
+    assert d.camera.medium_id == g["camera_medium_id"]
+    assert (d.options.integrator, d.options.vol_path_version, d.options.max_null_collisions, d.options.max_depth, d.options.rr_depth) == \
+           (g["integrator"], g["vol_path_version"], g["max_null_collisions"], g["max_depth"], g["rr_depth"])
+    assert [[d.shapes[i].material_id, d.shapes[i].interior_medium_id, d.shapes[i].exterior_medium_id] for i in range(d.n_shapes)] == g["shape_media"]
+    assert d.n_media == len(g["media"])
+    for i, gm in enumerate(g["media"]):
+        m = d.media[i]
+        assert m.kind == (_abi.LJ_MEDIUM_HOMOGENEOUS if gm["kind"] == "homogeneous" else _abi.LJ_MEDIUM_HETEROGENEOUS)
+        assert m.phase_kind == (_abi.LJ_PHASE_HG if gm["phase"] == "hg" else _abi.LJ_PHASE_ISOTROPIC) and m.g == gm["g"]
+        if gm["kind"] == "homogeneous":
+            assert list(m.sigma_a) == gm["sigma_a"] and list(m.sigma_s) == gm["sigma_s"]
+            continue
+        for vol, gv in ((m.albedo, gm["albedo"]), (m.density, gm["density"])):
+            if gv["kind"] == "constant":
+                assert vol.kind == _abi.LJ_VOLUME_CONSTANT and list(vol.value) == gv["value"]
+                continue
+            assert vol.kind == _abi.LJ_VOLUME_GRID and list(vol.resolution) == gv["resolution"]
+            assert list(vol.p_min) == gv["p_min"] and list(vol.p_max) == gv["p_max"] and list(vol.max_data) == gv["max_data"] and vol.scale == gv["scale"]
+            n = vol.resolution[0] * vol.resolution[1] * vol.resolution[2]
+            vox = np.ctypeslib.as_array(vol.data, shape=(n, 3)).astype(np.float64)
+            assert close(vox.sum(axis=0), gv["data_sum"], rel=1e-12)
+            st = max(1, n // 17)
+            assert np.array_equal(vox[::st], np.array(gv["samples"]))
