@@ -36,6 +36,7 @@ namespace {
 
 typedef double Real;
 const Real c_PI = Real(3.14159265358979323846);
+const Real c_INVFOURPI = Real(1.0) / (Real(4.0) * c_PI);  // lajolla.h
 const Real c_INVPI = Real(1.0) / c_PI;
 const Real c_TWOPI = Real(2.0) * c_PI;
 const Real c_INVTWOPI = Real(1.0) / c_TWOPI;
@@ -1406,6 +1407,303 @@ OScene *scene_create(const LjSceneDesc *d) {
 } // namespace
 
 // =================================================================== C entry points for the tests (ctypes)
+// ------------------------------------------------------------------ participating media
+inline Vector3 vmul(const Vector3 &a, const Vector3 &b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+inline Vector3 vdiv(const Vector3 &a, const Vector3 &b) { return {a.x / b.x, a.y / b.y, a.z / b.z}; }
+inline Vector3 vexp(const Vector3 &a) { return {std::exp(a.x), std::exp(a.y), std::exp(a.z)}; }
+inline Real vavg(const Vector3 &a) { return (a.x + a.y + a.z) / Real(3); }   // vector.h:259-262
+inline Real vget(const Vector3 &a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+inline Vector3 v3of(const double *d) { return {d[0], d[1], d[2]}; }
+
+// lookup(VolumeSpectrum, p) (volume.h:39-81): trilinear interpolation inside [p_min, p_max], zero outside
+Vector3 volume_lookup(const LjVolume &v, const Vector3 &p) {
+    if (v.kind == LJ_VOLUME_CONSTANT) return v3of(v.value);
+    Vector3 pn = vdiv(p - v3of(v.p_min), v3of(v.p_max) - v3of(v.p_min));
+    if (pn.x < 0 || pn.x > 1 || pn.y < 0 || pn.y > 1 || pn.z < 0 || pn.z > 1) return {0, 0, 0};
+    const int rx = v.resolution[0], ry = v.resolution[1], rz = v.resolution[2];
+    pn.x *= Real(rx - 1); pn.y *= Real(ry - 1); pn.z *= Real(rz - 1);
+    auto clampi = [](int a, int lo, int hi) { return a < lo ? lo : (a > hi ? hi : a); };
+    int x0 = clampi(int(pn.x), 0, rx - 1), y0 = clampi(int(pn.y), 0, ry - 1), z0 = clampi(int(pn.z), 0, rz - 1);
+    int x1 = clampi(x0 + 1, 0, rx - 1), y1 = clampi(y0 + 1, 0, ry - 1), z1 = clampi(z0 + 1, 0, rz - 1);
+    Real dx = pn.x - x0, dy = pn.y - y0, dz = pn.z - z0;
+    auto at = [&](int x, int y, int z) { const float *d = v.data + 3 * ((size_t)(z * ry + y) * rx + x); return Vector3{d[0], d[1], d[2]}; };
+    return v.scale * (at(x0, y0, z0) * ((1 - dx) * (1 - dy) * (1 - dz)) + at(x1, y0, z0) * (dx * (1 - dy) * (1 - dz)) +
+                      at(x0, y1, z0) * ((1 - dx) * dy * (1 - dz)) + at(x1, y1, z0) * (dx * dy * (1 - dz)) +
+                      at(x0, y0, z1) * ((1 - dx) * (1 - dy) * dz) + at(x1, y0, z1) * (dx * (1 - dy) * dz) +
+                      at(x0, y1, z1) * ((1 - dx) * dy * dz) + at(x1, y1, z1) * (dx * dy * dz));
+}
+// intersect(Volume, ray) (volume.h:118-144): slab test of the grid's box over [0, ray.tfar]
+bool volume_intersect(const LjVolume &v, const Ray &ray) {
+    if (v.kind == LJ_VOLUME_CONSTANT) return true;
+    Real t0 = 0, t1 = ray.tfar;
+    const Real o[3] = {ray.org.x, ray.org.y, ray.org.z}, d[3] = {ray.dir.x, ray.dir.y, ray.dir.z};
+    for (int i = 0; i < 3; i++) {
+        Real tn = (v.p_min[i] - o[i]) / d[i], tf = (v.p_max[i] - o[i]) / d[i];
+        if (tn > tf) std::swap(tn, tf);
+        t0 = tn > t0 ? tn : t0; t1 = tf < t1 ? tf : t1;
+        if (t0 > t1) return false;
+    }
+    return true;
+}
+Vector3 volume_max(const LjVolume &v) { return v.kind == LJ_VOLUME_CONSTANT ? v3of(v.value) : v.scale * v3of(v.max_data); }  // volume.h:83-97
+// medium.cpp:27-37 with media/homogeneous.inl, media/heterogeneous.inl
+Vector3 get_majorant(const LjMedium &m, const Ray &ray) {
+    if (m.kind == LJ_MEDIUM_HOMOGENEOUS) return v3of(m.sigma_a) + v3of(m.sigma_s);
+    return volume_intersect(m.density, ray) ? volume_max(m.density) : Vector3{0, 0, 0};
+}
+Vector3 get_sigma_s(const LjMedium &m, const Vector3 &p) {
+    if (m.kind == LJ_MEDIUM_HOMOGENEOUS) return v3of(m.sigma_s);
+    return vmul(volume_lookup(m.density, p), volume_lookup(m.albedo, p));
+}
+Vector3 get_sigma_a(const LjMedium &m, const Vector3 &p) {
+    if (m.kind == LJ_MEDIUM_HOMOGENEOUS) return v3of(m.sigma_a);
+    Vector3 a = volume_lookup(m.albedo, p);
+    return vmul(volume_lookup(m.density, p), Vector3{1 - a.x, 1 - a.y, 1 - a.z});
+}
+// phase_functions/isotropic.inl, henyeygreenstein.inl
+Real phase_eval(const LjMedium &m, const Vector3 &dir_in, const Vector3 &dir_out) {   // == pdf_sample_phase
+    if (m.phase_kind == LJ_PHASE_ISOTROPIC) return c_INVFOURPI;
+    const Real g = m.g;
+    return c_INVFOURPI * (1 - g * g) / std::pow(1 + g * g + 2 * g * dot(dir_in, dir_out), Real(3) / Real(2));
+}
+Vector3 phase_sample(const LjMedium &m, const Vector3 &dir_in, const Vector2 &rnd) {
+    const Real g = m.g;
+    if (m.phase_kind == LJ_PHASE_ISOTROPIC || std::fabs(g) < Real(1e-3)) {
+        Real z = 1 - 2 * rnd.x, r = std::sqrt(std::fmax(Real(0), 1 - z * z)), phi = 2 * c_PI * rnd.y;
+        return {r * std::cos(phi), r * std::sin(phi), z};
+    }
+    Real tmp = (g * g - 1) / (2 * rnd.x * g - (g + 1));
+    Real cos_el = (tmp * tmp - (1 + g * g)) / (2 * g);
+    Real sin_el = std::sqrt(std::max(1 - cos_el * cos_el, Real(0)));
+    Real az = 2 * c_PI * rnd.y;
+    return to_world(make_frame(dir_in), Vector3{sin_el * std::cos(az), sin_el * std::sin(az), cos_el});
+}
+
+// update_medium (vol_path_tracing.h:149-163)
+inline int update_medium(const OScene &s, const PathVertex &v, const Ray &ray, int medium) {
+    const LjShape &sh = s.shapes[v.shape_id];
+    if (sh.interior_medium_id != sh.exterior_medium_id) medium = dot(ray.dir, v.geometry_normal) > 0 ? sh.exterior_medium_id : sh.interior_medium_id;
+    return medium;
+}
+
+// next_event_estimation_final (vol_path_tracing.h:299-494).  The reference dereferences an empty optional at :344
+// (`shadow_vertex = *shadow_vertex_`); every later use of that value is guarded by the optional, so it is skipped here.
+Spectrum vol_nee(const OScene &scene, pcg32_state &rng, Vector3 p, int current_medium, int bounces, const Vector3 &dir_view,
+                 bool is_surface, const PathVertex &vertex, Counters *cnt, int *status) {
+    Vector2 light_uv; light_uv.x = next_pcg32_real(rng); light_uv.y = next_pcg32_real(rng);
+    Real light_w = next_pcg32_real(rng);
+    Real shape_w = next_pcg32_real(rng);
+    int light_id = sample_1d(scene.light_dist, light_w);
+    PointAndNormal pl = sample_point_on_light(scene, light_id, p, light_uv, shape_w);
+    Vector3 dir_light = normalize(pl.position - p);
+    const Vector3 p_prime = pl.position, p_origin = p;
+    const Real eps = shadow_epsilon(scene);
+    const int max_depth = scene.d.options.max_depth;
+    int shadow_medium = current_medium, shadow_bounces = 0;
+    Spectrum T{1, 1, 1}, p_trans_nee{1, 1, 1}, p_trans_dir{1, 1, 1};
+    for (;;) {
+        Ray shadow_ray{p, dir_light, eps, (1 - eps) * distance(p, p_prime)};
+        PathVertex sv; const bool hit = intersect(scene, shadow_ray, RayDifferential{0, 0}, sv, cnt);
+        Real next_t = distance(p, p_prime);
+        if (hit) next_t = distance(p, sv.position);
+        if (shadow_medium != -1) {
+            const LjMedium &med = scene.d.media[shadow_medium];
+            Vector3 majorant = get_majorant(med, shadow_ray);
+            Real u = next_pcg32_real(rng);
+            int channel = std::min(std::max(int(u * 3), 0), 2);
+            Real accum_t = 0; int iteration = 0;
+            for (;;) {
+                if (vget(majorant, channel) <= 0) break;
+                if (iteration >= scene.d.options.max_null_collisions) break;
+                Real t = -std::log(1 - next_pcg32_real(rng)) / vget(majorant, channel);
+                Real dt = next_t - accum_t;
+                accum_t = std::min(accum_t + t, next_t);
+                if (t < dt) {
+                    Vector3 pos = p + dir_light * accum_t;
+                    Vector3 sigma_t = get_sigma_s(med, pos) + get_sigma_a(med, pos);
+                    Vector3 ratio = vdiv(sigma_t, majorant);
+                    Vector3 sigma_n = vmul(majorant, Vector3{1 - ratio.x, 1 - ratio.y, 1 - ratio.z});
+                    Vector3 e = vexp(-(majorant * t));
+                    Real mx = vmax(majorant);
+                    T = vmul(T, vmul(e, sigma_n) / mx);
+                    p_trans_nee = vmul(p_trans_nee, vmul(e, majorant) / mx);
+                    p_trans_dir = vmul(p_trans_dir, vmul(vmul(e, majorant), Vector3{1 - ratio.x, 1 - ratio.y, 1 - ratio.z}) / mx);
+                    if (vmax(T) <= 0) break;
+                } else {
+                    Vector3 e = vexp(-(majorant * dt));
+                    T = vmul(T, e); p_trans_nee = vmul(p_trans_nee, e); p_trans_dir = vmul(p_trans_dir, e);
+                    break;
+                }
+                iteration++;
+            }
+        }
+        if (!hit) break;
+        if (sv.material_id >= 0) return {0, 0, 0};   // an opaque surface blocks the light
+        shadow_bounces++;                             // an index-matched surface: pass through, one more connection vertex
+        if (max_depth != -1 && bounces + shadow_bounces >= max_depth) return {0, 0, 0};
+        shadow_medium = update_medium(scene, sv, shadow_ray, shadow_medium);
+        p = p + next_t * dir_light;
+    }
+    if (!(vmax(T) > 0)) return {0, 0, 0};
+    Spectrum Le = light_emission(scene, light_id, -dir_light, Real(0), pl);
+    Real jacobian = std::max(-dot(dir_light, pl.normal), Real(0)) / distance_squared(p_origin, p_prime);
+    Spectrum pdf_nee = (scene.light_dist.pmf[light_id] * pdf_point_on_light(scene, light_id, pl, p_origin)) * p_trans_nee;
+    Spectrum f, pdf_dir;
+    if (is_surface) {
+        const LjMaterial &mat = scene.materials[vertex.material_id];
+        if (!bsdf_eval(&scene, mat, dir_view, dir_light, vertex, f)) { *status = 1; return {0, 0, 0}; }
+        Real pdf_bsdf; if (!bsdf_pdf(&scene, mat, dir_view, dir_light, vertex, pdf_bsdf)) { *status = 1; return {0, 0, 0}; }
+        if (pdf_bsdf <= 0) return {0, 0, 0};
+        pdf_dir = (pdf_bsdf * jacobian) * p_trans_dir;
+    } else {
+        const LjMedium &med = scene.d.media[current_medium];
+        next_pcg32_real(rng); next_pcg32_real(rng);   // phase_uv: drawn and never used (vol_path_tracing.h:475)
+        Real ph = phase_eval(med, dir_view, dir_light);
+        f = {ph, ph, ph};
+        pdf_dir = (ph * jacobian) * p_trans_dir;
+    }
+    Spectrum contrib = vmul(vmul(T, f), Le) * jacobian / vavg(pdf_nee);
+    Spectrum n2 = vmul(pdf_nee, pdf_nee), d2 = vmul(pdf_dir, pdf_dir);
+    Spectrum w = vdiv(n2, n2 + d2);
+    return vmul(contrib, w);
+}
+
+// vol_path_tracing (vol_path_tracing.h:503-869), the final renderer; the earlier versions (vol_path_tracing_1..5, the
+// homework's intermediate steps) are special cases of it and are rendered with it — same expectation, more variance.
+// Reference quirks kept: a ray that leaves the scene from vacuum returns ZERO, not the radiance gathered so far (:626);
+// an emitter reached by phase / BSDF sampling is weighted with a geometry term of the wrong sign, i.e. zero for a
+// front-facing hit (:688-695); no pdf > 0 check after BSDF sampling (:836-841).  nee_p_cache is read before it is
+// first written (:520, uninitialised in the reference): zero here.
+Spectrum vol_path_tracing(const OScene &scene, int x, int y, pcg32_state &rng, Counters *cnt, int *status) {
+    const LjCamera &cam = scene.d.camera;
+    const int w = cam.width, h = cam.height;
+    Real jy = next_pcg32_real(rng);   // g++ evaluates the constructor arguments right to left
+    Real jx = next_pcg32_real(rng);
+    Ray ray = sample_primary(scene, Vector2{(x + jx) / w, (y + jy) / h});
+    ray.tnear = shadow_epsilon(scene);   // get_intersection_epsilon == get_shadow_epsilon (scene.h:99-105)
+    RayDifferential ray_diff{0, 0};
+    if (cnt) cnt->samples++;
+    const LjRenderOptions &opt = scene.d.options;
+    int current_medium = cam.medium_id;
+    Spectrum throughput{1, 1, 1}, radiance{0, 0, 0};
+    int bounces = 0;
+    Real dir_pdf = 0; Vector3 nee_p_cache{0, 0, 0};
+    Spectrum multi_trans_pdf{1, 1, 1};
+    Real eta_scale = 1;
+    for (;;) {
+        bool scatter = false;
+        PathVertex vertex; const bool hit = intersect(scene, ray, ray_diff, vertex, cnt);
+        Real t_hit = hit ? distance(vertex.position, ray.org) : std::numeric_limits<Real>::infinity();
+        Spectrum transmittance{1, 1, 1}, trans_dir_pdf{1, 1, 1}, trans_nee_pdf{1, 1, 1};
+        if (current_medium != -1) {
+            const LjMedium &med = scene.d.media[current_medium];
+            Vector3 majorant = get_majorant(med, ray);
+            Real u = next_pcg32_real(rng);
+            int channel = std::min(std::max(int(u * 3), 0), 2);
+            Real accum_t = 0; int iteration = 0;
+            for (;;) {
+                if (vget(majorant, channel) <= 0) break;
+                if (iteration >= opt.max_null_collisions) break;
+                Real t = -std::log(1 - next_pcg32_real(rng)) / vget(majorant, channel);
+                Real dt = t_hit - accum_t;
+                accum_t = std::min(accum_t + t, t_hit);
+                if (t < dt) {
+                    Vector3 p = ray.org + ray.dir * accum_t;
+                    Vector3 sigma_t = get_sigma_s(med, p) + get_sigma_a(med, p);
+                    Vector3 real_prob = vdiv(sigma_t, majorant);
+                    Vector3 one_minus{1 - real_prob.x, 1 - real_prob.y, 1 - real_prob.z};
+                    Vector3 sigma_n = vmul(majorant, one_minus);
+                    Vector3 e = vexp(-(majorant * t));
+                    Real mx = vmax(majorant);
+                    if (next_pcg32_real(rng) < vget(real_prob, channel)) {   // a real particle
+                        scatter = true;
+                        transmittance = vmul(transmittance, e / mx);
+                        trans_dir_pdf = vmul(trans_dir_pdf, vmul(vmul(e, majorant), real_prob) / mx);
+                        ray.org = p;
+                        break;
+                    }
+                    transmittance = vmul(transmittance, vmul(e, sigma_n) / mx);
+                    trans_dir_pdf = vmul(trans_dir_pdf, vmul(vmul(e, majorant), one_minus) / mx);
+                    trans_nee_pdf = vmul(trans_nee_pdf, vmul(e, majorant) / mx);
+                } else {
+                    Vector3 e = vexp(-(majorant * dt));
+                    transmittance = vmul(transmittance, e); trans_dir_pdf = vmul(trans_dir_pdf, e); trans_nee_pdf = vmul(trans_nee_pdf, e);
+                    ray.org = vertex.position;
+                    break;
+                }
+                iteration++;
+            }
+            multi_trans_pdf = vmul(multi_trans_pdf, trans_dir_pdf);
+        } else {
+            if (hit) ray.org = vertex.position;
+            else return {0, 0, 0};
+        }
+        throughput = vmul(throughput, transmittance / vavg(trans_dir_pdf));
+        if (!scatter && hit && scene.shapes[vertex.shape_id].area_light_id >= 0) {
+            Spectrum Le = vertex_emission(scene, vertex, -ray.dir);
+            if (bounces == 0) { radiance += vmul(throughput, Le); return radiance; }
+            const int light_id = scene.shapes[vertex.shape_id].area_light_id;
+            PointAndNormal light_point{vertex.position, vertex.geometry_normal};
+            Spectrum pdf_nee = (scene.light_dist.pmf[light_id] * pdf_point_on_light(scene, light_id, light_point, nee_p_cache)) * trans_nee_pdf;
+            Real jacobian = std::max(-dot(-ray.dir, light_point.normal), Real(0)) / distance_squared(nee_p_cache, light_point.position);
+            Spectrum pdf_phase = (dir_pdf * jacobian) * multi_trans_pdf;
+            Spectrum p2 = vmul(pdf_phase, pdf_phase), n2 = vmul(pdf_nee, pdf_nee);
+            Spectrum wgt = vdiv(p2, p2 + n2);
+            radiance += vmul(vmul(throughput, Le), wgt);
+        }
+        if (!scatter && hit && vertex.material_id == -1) {   // index-matched surface: change medium, go on
+            current_medium = update_medium(scene, vertex, ray, current_medium);
+            ray.org = vertex.position;
+            bounces++;
+            continue;
+        }
+        if (bounces >= opt.max_depth - 1 && opt.max_depth != -1) break;
+        if (cnt) cnt->bounces++;
+        if (scatter && current_medium != -1) {
+            const LjMedium &med = scene.d.media[current_medium];
+            Vector3 sigma_s = get_sigma_s(med, ray.org);
+            Spectrum nee = vol_nee(scene, rng, ray.org, current_medium, bounces, -ray.dir, false, vertex, cnt, status);
+            radiance += vmul(vmul(throughput, sigma_s), nee);
+            if (vmax(nee) > 0) nee_p_cache = ray.org;
+            Vector2 phase_uv; phase_uv.x = next_pcg32_real(rng); phase_uv.y = next_pcg32_real(rng);
+            Vector3 next_dir = phase_sample(med, -ray.dir, phase_uv);
+            Real phase_pdf = phase_eval(med, -ray.dir, next_dir);
+            throughput = vmul(throughput, (phase_pdf / phase_pdf) * sigma_s);   // eval / pdf, as written (:793-795)
+            ray.dir = next_dir;
+            dir_pdf = phase_pdf;
+            multi_trans_pdf = {1, 1, 1};
+        } else if (hit) {
+            Spectrum nee = vol_nee(scene, rng, ray.org, current_medium, bounces, -ray.dir, true, vertex, cnt, status);
+            radiance += vmul(throughput, nee);
+            if (vmax(nee) > 0) nee_p_cache = ray.org;
+            const LjMaterial &mat = scene.materials[vertex.material_id];
+            Vector3 dir_view = -ray.dir;
+            Vector2 bsdf_uv; bsdf_uv.x = next_pcg32_real(rng); bsdf_uv.y = next_pcg32_real(rng);
+            Real bsdf_w = next_pcg32_real(rng);
+            BSDFSampleRecord rec; bool ok;
+            if (!bsdf_sample(&scene, mat, dir_view, vertex, bsdf_uv, bsdf_w, ok, rec)) { *status = 1; return {0, 0, 0}; }
+            if (!ok) break;
+            ray.dir = rec.dir_out;
+            if (rec.eta == 0) ray_diff.spread = rd_reflect(ray_diff, vertex.mean_curvature, rec.roughness);
+            else {
+                ray_diff.spread = rd_refract(ray_diff, vertex.mean_curvature, rec.eta, rec.roughness);
+                eta_scale /= (rec.eta * rec.eta);
+                current_medium = update_medium(scene, vertex, ray, current_medium);
+            }
+            Spectrum f; if (!bsdf_eval(&scene, mat, dir_view, rec.dir_out, vertex, f)) { *status = 1; return {0, 0, 0}; }
+            Real pdf_bsdf; if (!bsdf_pdf(&scene, mat, dir_view, rec.dir_out, vertex, pdf_bsdf)) { *status = 1; return {0, 0, 0}; }
+            throughput = vmul(throughput, f / pdf_bsdf);
+        }
+        if (bounces >= opt.rr_depth) {
+            Real rr_prob = std::min(vmax((1 / eta_scale) * throughput), Real(0.95));
+            if (next_pcg32_real(rng) > rr_prob) break;
+            throughput = throughput / rr_prob;
+        }
+        bounces++;
+    }
+    return radiance;
+}
+
 // render.cpp:12-69 aux_render: one primary ray through the pixel centre, no RNG
 static Vector3 aux_pixel(const OScene &s, int x, int y, Counters *cnt) {
     const int w = s.d.camera.width, h = s.d.camera.height;
@@ -1597,6 +1895,24 @@ typedef struct OracleRenderArgs {
 typedef struct OracleStats { uint64_t samples, bounces, rays_closest, rays_shadow; double seconds; int32_t status; } OracleStats;
 
 // rgb: w*h*3 doubles (radiance / spp, render.cpp:94); per_sample (optional): crop_w*crop_h*spp*3 doubles, sample mode only
+// media known-answer hooks
+void oracle_phase(int phase_kind, double g, const double *dir_in, const double *dir_out, const double *uv, double *eval_out, double *sample3) {
+    LjMedium m{}; m.phase_kind = phase_kind; m.g = g;
+    *eval_out = phase_eval(m, v3of(dir_in), v3of(dir_out));
+    Vector3 smp = phase_sample(m, v3of(dir_in), Vector2{uv[0], uv[1]});
+    sample3[0] = smp.x; sample3[1] = smp.y; sample3[2] = smp.z;
+}
+void oracle_medium_point(void *sv, int medium_id, const double *p, double *sigma_s3, double *sigma_a3) {
+    const LjMedium &m = ((OScene *)sv)->d.media[medium_id];
+    Vector3 a = get_sigma_s(m, v3of(p)), b = get_sigma_a(m, v3of(p));
+    sigma_s3[0] = a.x; sigma_s3[1] = a.y; sigma_s3[2] = a.z; sigma_a3[0] = b.x; sigma_a3[1] = b.y; sigma_a3[2] = b.z;
+}
+void oracle_medium_majorant(void *sv, int medium_id, const double *org, const double *dir, double tfar, double *out3) {
+    const LjMedium &m = ((OScene *)sv)->d.media[medium_id];
+    Vector3 r = get_majorant(m, Ray{v3of(org), v3of(dir), Real(0), tfar});
+    out3[0] = r.x; out3[1] = r.y; out3[2] = r.z;
+}
+
 int oracle_render(void *sv, const OracleRenderArgs *a, double *rgb, double *per_sample, OracleStats *stats) {
     OScene *s = (OScene *)sv;
     const int w = s->d.camera.width, h = s->d.camera.height;
@@ -1625,7 +1941,7 @@ int oracle_render(void *sv, const OracleRenderArgs *a, double *rgb, double *per_
                 bool inside = x >= cx0 && x < cx1 && y >= cy0 && y < cy1;
                 if (!inside && a->rng_mode == 0) continue;
                 Spectrum radiance{0, 0, 0};
-                if (s->d.options.integrator != LJ_INTEGRATOR_PATH) {  // aux buffers: one deterministic value per pixel
+                if (s->d.options.integrator < LJ_INTEGRATOR_PATH) {  // aux buffers: one deterministic value per pixel
                     if (!inside) continue;
                     Vector3 c = aux_pixel(*s, x, y, &cnt);
                     size_t o = ((size_t)y * w + x) * 3; rgb[o] = c.x; rgb[o + 1] = c.y; rgb[o + 2] = c.z;
@@ -1634,7 +1950,8 @@ int oracle_render(void *sv, const OracleRenderArgs *a, double *rgb, double *per_
                 for (int sidx = 0; sidx < spp; sidx++) {
                     int st = 0;
                     if (a->rng_mode == 0) rng = init_pcg32(((uint64_t)y * w + x) * (uint64_t)spp + sidx, seed);
-                    Spectrum L = path_tracing(*s, x, y, rng, a->max_depth, a->use_max_depth != 0, &cnt, &st);
+                    Spectrum L = s->d.options.integrator == LJ_INTEGRATOR_VOLPATH ? vol_path_tracing(*s, x, y, rng, &cnt, &st)
+                                                                                   : path_tracing(*s, x, y, rng, a->max_depth, a->use_max_depth != 0, &cnt, &st);
                     if (st) status.store(st);
                     radiance += L;
                     if (per_sample && inside) {

@@ -66,6 +66,13 @@ def oracle_lib():
     return _oracle
 
 
+def oracle_phase(phase_kind, g, dir_in, dir_out, uv):
+    ev = C.c_double()
+    smp = np.zeros(3)
+    oracle_lib().oracle_phase(C.c_int(phase_kind), C.c_double(g), dptr(darr(dir_in)), dptr(darr(dir_out)), dptr(darr(uv)), C.byref(ev), dptr(smp))
+    return ev.value, smp
+
+
 class Oracle:
     """CPU restatement of the reference, built from an LjSceneDesc (keeps the HostScene alive)."""
 
@@ -120,6 +127,16 @@ class Oracle:
         rc = self.lib.oracle_bsdf(self.h, C.byref(material), dptr(darr(vertex22)), dptr(darr(dir_in)), dptr(darr(dir_out)), dptr(darr(rnd_uv)),
                                   C.c_double(rnd_w), C.c_int(to_view), dptr(ev), C.byref(pdf), C.byref(valid), dptr(sd), C.byref(eta), C.byref(rough))
         return rc, ev, pdf.value, valid.value, sd, eta.value, rough.value
+
+    def medium_point(self, medium_id, p):
+        ss, sa = np.zeros(3), np.zeros(3)
+        self.lib.oracle_medium_point(self.h, C.c_int(medium_id), dptr(darr(p)), dptr(ss), dptr(sa))
+        return ss, sa
+
+    def medium_majorant(self, medium_id, org, d, tfar):
+        out = np.zeros(3)
+        self.lib.oracle_medium_majorant(self.h, C.c_int(medium_id), dptr(darr(org)), dptr(darr(d)), C.c_double(tfar), dptr(out))
+        return out
 
     def intersect(self, rays):
         hits = np.zeros(rays.shape[0], lj.HIT_DTYPE)

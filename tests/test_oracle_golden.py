@@ -260,3 +260,33 @@ def test_reference_intersection_fixture():
     assert hit == 1 and sid.value == 0 and pid.value == 0
     assert np.linalg.norm(out[:3] - np.array([0, 0, -1])) < 1e-3
     lib.oracle_scene_free(h)
+
+
+# ------------------------------------------------------------------ participating media
+def test_phase_functions_match_reference():
+    """phase_functions/isotropic.inl, henyeygreenstein.inl: eval == pdf, and the sampled direction."""
+    from helpers import oracle_phase
+    for ph in golden("media")["phase"]:
+        kind = 0 if ph["isotropic"] else 1
+        for c in ph["cases"]:
+            ev, smp = oracle_phase(kind, ph["g"], c["dir_in"], c["dir_out"], c["uv"])
+            assert close(ev, c["pdf"]) and close([ev] * 3, c["eval"])
+            assert close(smp, c["sample"])
+
+
+@pytest.mark.parametrize("name", ["hetvol", "hetvol_colored", "vol_cbox_teapot", "volpath_test6"])
+def test_medium_queries_match_reference(name):
+    """get_majorant / get_sigma_s / get_sigma_a (medium.cpp:27-37, media/*.inl) incl. the grid volume's trilinear lookup
+    and box test (volume.h:39-81,118-144)."""
+    import os
+    from helpers import ROOT
+    g = golden("media")["scenes"][name]
+    hs = lj.parse_scene(os.path.join(ROOT, "scenes", "volpath_test", name + ".xml"))
+    o = Oracle(hs)
+    for mi, gm in enumerate(g["media"]):
+        for q in gm["points"]:
+            ss, sa = o.medium_point(mi, q["p"])
+            assert close(ss, q["sigma_s"]) and close(sa, q["sigma_a"])
+        for q in gm["rays"]:
+            tfar = np.inf if q["tfar"] == "inf" else q["tfar"]
+            assert close(o.medium_majorant(mi, q["org"], q["dir"], tfar), q["majorant"])
