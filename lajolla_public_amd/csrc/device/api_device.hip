@@ -23,6 +23,7 @@ void launch_extend(const DScene &sc, const DQueue &q, const DBlockState *blocks,
 void launch_shade(const DScene &sc, const DPass &pass, const DQueue &q, DBlockState *blocks, uint32_t n_blocks, uint32_t seg, const ShadeConfig &cfg, uint32_t *work, uint32_t *chunk_list, uint32_t parity, uint32_t extend_waves, hipStream_t s);
 void launch_resolve(const DPass &pass, uint32_t n_pixels, float *rgb, hipStream_t s);
 void launch_aux(const DScene &sc, const uint32_t *pixel_list, uint32_t n_pixels, int integrator, float *rgb, const ExtendConfig &cfg, int *spill, int grid, hipStream_t s);
+void launch_volpath(const DScene &sc, const DPass &pass, uint32_t n_samples, unsigned long long *bounce_counter, const ExtendConfig &cfg, int *spill, int grid, hipStream_t s);
 void launch_trace_rays(const DScene &sc, const void *rays, long long n, void *hits, unsigned char *occ, const ExtendConfig &cfg, int *spill, int grid, hipStream_t s);
 }
 
@@ -155,7 +156,7 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
     const uint64_t n_pix = plan.pixels.size();
     LjStats &st = sc->stats; st = LjStats{};
     if (n_pix == 0) return;
-    if (sc->flat.integrator != LJ_INTEGRATOR_PATH) {   // auxiliary buffers: one primary ray per pixel, no queue
+    if (sc->flat.integrator < LJ_INTEGRATOR_PATH) {   // auxiliary buffers: one primary ray per pixel, no queue
         if (samples_host) throw LjError(LJ_ERR_UNSUPPORTED, "the auxiliary integrators have one deterministic value per pixel, no per-sample values");
         if (ctx->pixel_list.bytes < n_pix * 4) ctx->pixel_list.alloc(n_pix * 4);
         HIP_CHECK(hipMemcpyAsync(ctx->pixel_list.p, plan.pixels.data(), n_pix * 4, hipMemcpyHostToDevice, stream));
@@ -174,6 +175,39 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
     const uint64_t max_samples_pass = (uint64_t)1 << 27;
     uint64_t pix_per_pass = std::max<uint64_t>(1, max_samples_pass / (uint64_t)plan.spp);
     pix_per_pass = std::min<uint64_t>(pix_per_pass, n_pix);
+    if (sc->flat.integrator == LJ_INTEGRATOR_VOLPATH) {   // volumetric path tracer: one lane per sample, whole path (dvol.h)
+        const uint64_t pass_samples_max = pix_per_pass * (uint64_t)plan.spp;
+        if (ctx->sample_rgb.bytes < pass_samples_max * 12) ctx->sample_rgb.alloc(pass_samples_max * 12);
+        if (ctx->pixel_list.bytes < n_pix * 4) ctx->pixel_list.alloc(n_pix * 4);
+        if (!ctx->chunk_counter.p) ctx->chunk_counter.alloc(512);
+        HIP_CHECK(hipMemcpyAsync(ctx->pixel_list.p, plan.pixels.data(), n_pix * 4, hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipMemsetAsync(ctx->chunk_counter.p, 0, 8, stream));
+        HIP_CHECK(hipEventRecord(ctx->ev_begin, stream));
+        for (uint64_t p0 = 0; p0 < n_pix; p0 += pix_per_pass) {
+            const uint64_t np = std::min<uint64_t>(pix_per_pass, n_pix - p0);
+            const uint64_t total = np * (uint64_t)plan.spp;
+            ljd::DPass pass{};
+            pass.pixel_list = (const uint32_t *)ctx->pixel_list.p + p0; pass.n_pixels = (uint32_t)np; pass.spp = (uint32_t)plan.spp;
+            pass.seed = plan.seed; pass.sample_rgb = (float *)ctx->sample_rgb.p;
+            const int grid = (int)std::min<uint64_t>((total + 255) / 256, (uint64_t)ctx->n_cus * 16);
+            ljd::launch_volpath(ds, pass, (uint32_t)total, (unsigned long long *)ctx->chunk_counter.p, sc->ecfg,
+                                ensure_spill(ctx, sc->ecfg.spill_levels, (uint32_t)grid), grid, stream);
+            HIP_CHECK(hipGetLastError());
+            st.samples += total;
+            if (rgb_dev) ljd::launch_resolve(pass, (uint32_t)np, rgb_dev, stream);
+            if (samples_host) {
+                HIP_CHECK(hipMemcpyAsync(samples_host + p0 * (uint64_t)plan.spp * 3, ctx->sample_rgb.p, total * 12, hipMemcpyDeviceToHost, stream));
+                HIP_CHECK(hipStreamSynchronize(stream));
+            }
+        }
+        HIP_CHECK(hipEventRecord(ctx->ev_end, stream));
+        HIP_CHECK(hipEventSynchronize(ctx->ev_end));
+        float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
+        unsigned long long nb = 0;
+        HIP_CHECK(hipMemcpy(&nb, ctx->chunk_counter.p, 8, hipMemcpyDeviceToHost));
+        st.render_ms = ms; st.bounce_iterations = nb;
+        return;
+    }
     // queue geometry: n_blocks workgroups x seg slots; workgroup b owns slots [b*seg, (b+1)*seg)
     const uint64_t pass_samples_max = pix_per_pass * (uint64_t)plan.spp;
     uint32_t pool = (uint32_t)std::min<uint64_t>(plan.pool, std::max<uint64_t>(pass_samples_max, 256));

@@ -92,6 +92,22 @@ struct DCamera {
     float filter_param;
 };
 
+// ---- participating media (medium.h:10-21, volume.h:13-30); grid voxels live in DScene::volume_data, 3 floats each
+struct DVolume {
+    int32_t kind;                    // 0 constant, 1 grid
+    int32_t res[3];
+    float value[3];                  // constant (medium scale applied)
+    float p_min[3], p_max[3], max_data[3];
+    float scale;
+    int64_t offset;                  // of the first voxel, in floats
+};
+struct DMedium {
+    int32_t kind, phase_kind;        // 0 homogeneous / 1 heterogeneous; 0 isotropic / 1 Henyey-Greenstein
+    float g;
+    float sigma_a[3], sigma_s[3];
+    DVolume albedo, density;
+};
+
 struct DScene {
     DCamera cam;
     const DNode4 *nodes; int32_t n_nodes;
@@ -110,6 +126,11 @@ struct DScene {
     int32_t max_depth, rr_depth;
     float eps;                       // get_shadow_epsilon == get_intersection_epsilon (scene.h:99-105)
     float init_spread;               // 0.25 / max(w, h)  (ray.h:35-37)
+    // volumetric path tracer only (dvol.h)
+    const DMedium *media; int32_t n_media;
+    const float *volume_data;
+    const int32_t *shape_media;      // per shape: interior, exterior medium id (-1: none)
+    int32_t cam_medium, max_null_collisions;
 };
 
 // ---- wavefront path queue: one slot per in-flight path, stored as eight arrays of 16-byte records so that every

@@ -1,0 +1,306 @@
+// Participating media on the device: Medium / PhaseFunction / Volume queries (medium.cpp:27-37, media/*.inl,
+// phase_functions/*.inl, volume.h:39-144) and the final volumetric path tracer vol_path_tracing with its
+// next_event_estimation_final (vol_path_tracing.h:149-163, 299-494, 503-869) — SURVEY row a31, "build last".
+//
+// Unlike path_tracing, this integrator is not cut into wavefront kernels: a sample walks its whole path in one lane
+// (k_volpath), tracing closest hits through the `Tracer` it is handed.  The control flow — free-flight sampling with
+// null collisions, shadow connections that pass through index-matched surfaces, medium bookkeeping — is a chain of
+// data-dependent loops with several ray casts per bounce; parity with the reference is statistical only, and
+// no BASELINE config uses it, so it is built for correctness, not for the roofline.
+//
+// Tracer provides:  bool closest(f3 org, f3 dir, float tnear, float tfar, float &t, float &u, float &v, int &gprim);
+#pragma once
+#include "dshade.h"
+
+namespace ljd {
+
+LJ_HD f3 vexp3(f3 a) { return mk3(expf(a.x), expf(a.y), expf(a.z)); }
+// exp(-majorant * t) with its largest channel scaled to one.  Every quantity a free-flight loop accumulates (the
+// transmittance and the two pdfs) carries the same product of these factors and only ever enters the estimator through
+// ratios of them, so a common scalar cancels exactly — but unscaled, a long chain of null collisions underflows float
+// to 0 / 0 (the reference's doubles have 270 more decades).
+LJ_HD f3 vexp3_scaled(f3 a) {
+    const float m = fmaxf(fmaxf(a.x, a.y), a.z);
+    return mk3(expf(a.x - m), expf(a.y - m), expf(a.z - m));
+}
+LJ_HD f3 vdiv3(f3 a, f3 b) { return mk3(a.x / b.x, a.y / b.y, a.z / b.z); }
+LJ_HD float vget3(f3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+LJ_HD float vavg3(f3 a) { return (a.x + a.y + a.z) / 3.0f; }
+
+// lookup(VolumeSpectrum, p) (volume.h:39-81)
+LJ_HD f3 volume_lookup(const DScene &sc, const DVolume &v, f3 p) {
+    if (v.kind == 0) return ld3(v.value);
+    f3 pn = vdiv3(p - ld3(v.p_min), ld3(v.p_max) - ld3(v.p_min));
+    if (pn.x < 0.0f || pn.x > 1.0f || pn.y < 0.0f || pn.y > 1.0f || pn.z < 0.0f || pn.z > 1.0f) return mk3(0, 0, 0);
+    const int rx = v.res[0], ry = v.res[1], rz = v.res[2];
+    pn.x *= (float)(rx - 1); pn.y *= (float)(ry - 1); pn.z *= (float)(rz - 1);
+    auto clampi = [](int a, int lo, int hi) { return a < lo ? lo : (a > hi ? hi : a); };
+    const int x0 = clampi((int)pn.x, 0, rx - 1), y0 = clampi((int)pn.y, 0, ry - 1), z0 = clampi((int)pn.z, 0, rz - 1);
+    const int x1 = clampi(x0 + 1, 0, rx - 1), y1 = clampi(y0 + 1, 0, ry - 1), z1 = clampi(z0 + 1, 0, rz - 1);
+    const float dx = pn.x - x0, dy = pn.y - y0, dz = pn.z - z0;
+    const float *base = sc.volume_data + v.offset;
+    auto at = [&](int x, int y, int z) { return ld3(base + 3 * ((size_t)(z * ry + y) * rx + x)); };
+    return (at(x0, y0, z0) * ((1 - dx) * (1 - dy) * (1 - dz)) + at(x1, y0, z0) * (dx * (1 - dy) * (1 - dz)) +
+            at(x0, y1, z0) * ((1 - dx) * dy * (1 - dz)) + at(x1, y1, z0) * (dx * dy * (1 - dz)) +
+            at(x0, y0, z1) * ((1 - dx) * (1 - dy) * dz) + at(x1, y0, z1) * (dx * (1 - dy) * dz) +
+            at(x0, y1, z1) * ((1 - dx) * dy * dz) + at(x1, y1, z1) * (dx * dy * dz)) * v.scale;
+}
+// intersect(Volume, ray) (volume.h:118-144)
+LJ_HD bool volume_intersect(const DVolume &v, f3 org, f3 dir, float tfar) {
+    if (v.kind == 0) return true;
+    float t0 = 0.0f, t1 = tfar;
+    const float o[3] = {org.x, org.y, org.z}, d[3] = {dir.x, dir.y, dir.z};
+    for (int i = 0; i < 3; i++) {
+        float tn = (v.p_min[i] - o[i]) / d[i], tf = (v.p_max[i] - o[i]) / d[i];
+        if (tn > tf) { const float s = tn; tn = tf; tf = s; }
+        t0 = tn > t0 ? tn : t0; t1 = tf < t1 ? tf : t1;
+        if (t0 > t1) return false;
+    }
+    return true;
+}
+LJ_HD f3 get_majorant(const DMedium &m, f3 org, f3 dir, float tfar) {
+    if (m.kind == 0) return ld3(m.sigma_a) + ld3(m.sigma_s);
+    if (!volume_intersect(m.density, org, dir, tfar)) return mk3(0, 0, 0);
+    return m.density.kind == 0 ? ld3(m.density.value) : ld3(m.density.max_data) * m.density.scale;
+}
+LJ_HD void get_sigmas(const DScene &sc, const DMedium &m, f3 p, f3 &sigma_s, f3 &sigma_a) {
+    if (m.kind == 0) { sigma_s = ld3(m.sigma_s); sigma_a = ld3(m.sigma_a); return; }
+    const f3 density = volume_lookup(sc, m.density, p), albedo = volume_lookup(sc, m.albedo, p);
+    sigma_s = density * albedo; sigma_a = density * (mk3(1, 1, 1) - albedo);
+}
+// phase_functions/*.inl: eval == pdf_sample_phase
+LJ_HD float phase_eval(const DMedium &m, f3 dir_in, f3 dir_out) {
+    const float inv4pi = 0.25f * kInvPi;
+    if (m.phase_kind == 0) return inv4pi;
+    const float g = m.g;
+    const float b = 1.0f + g * g + 2.0f * g * dot(dir_in, dir_out);
+    return inv4pi * (1.0f - g * g) / (b * sqrtf(b));
+}
+LJ_HD f3 phase_sample(const DMedium &m, f3 dir_in, float r0, float r1) {
+    const float g = m.g;
+    if (m.phase_kind == 0 || fabsf(g) < 1e-3f) {
+        const float z = 1.0f - 2.0f * r0, r = sqrtf(fmaxf(0.0f, 1.0f - z * z)), phi = kTwoPi * r1;
+        return mk3(r * cosf(phi), r * sinf(phi), z);
+    }
+    const float tmp = (g * g - 1.0f) / (2.0f * r0 * g - (g + 1.0f));
+    const float cos_el = (tmp * tmp - (1.0f + g * g)) / (2.0f * g);
+    const float sin_el = sqrtf(fmaxf(1.0f - cos_el * cos_el, 0.0f));
+    const float az = kTwoPi * r1;
+    return to_world(make_frame(dir_in), mk3(sin_el * cosf(az), sin_el * sinf(az), cos_el));
+}
+
+// update_medium (vol_path_tracing.h:149-163)
+LJ_HD int update_medium(const DScene &sc, const DVertex &vx, f3 dir, int medium) {
+    const int shape = sc.prims[vx.gprim].shape_id;
+    const int interior = sc.shape_media[2 * shape], exterior = sc.shape_media[2 * shape + 1];
+    if (interior != exterior) medium = dot(dir, vx.gn) > 0.0f ? exterior : interior;
+    return medium;
+}
+
+struct VolRng { uint64_t state, inc; };
+LJ_HD float vrnd(VolRng &r) { return pcg32_real(r.state, r.inc); }
+
+// next_event_estimation_final (vol_path_tracing.h:299-494)
+template <class Tracer>
+LJ_HD f3 vol_nee(const DScene &sc, Tracer &tr, VolRng &rng, f3 p, int current_medium, int bounces, f3 dir_view, bool is_surface, const DVertex &vertex) {
+    const float lu0 = vrnd(rng), lu1 = vrnd(rng), light_w = vrnd(rng), shape_w = vrnd(rng);
+    const int light_id = sample_cdf(sc.light_cdf, sc.n_lights, light_w);
+    const DLight &Lt = sc.lights[light_id];
+    const LightSample pl = sample_point_on_light(sc, Lt, p, lu0, lu1, shape_w);
+    const f3 dir_light = normalize(pl.position - p);
+    const f3 p_prime = pl.position, p_origin = p;
+    int shadow_medium = current_medium, shadow_bounces = 0;
+    f3 T = mk3(1, 1, 1), p_trans_nee = mk3(1, 1, 1), p_trans_dir = mk3(1, 1, 1);
+    for (;;) {
+        const float dist_to_light = length(p_prime - p);
+        float t, hu, hv; int gprim;
+        const bool hit = tr.closest(p, dir_light, sc.eps, (1.0f - sc.eps) * dist_to_light, t, hu, hv, gprim);
+        DVertex sv;
+        float next_t = dist_to_light;
+        if (hit) { sv = build_vertex(sc, p, dir_light, t, hu, hv, gprim, 0.0f); next_t = length(sv.position - p); }
+        if (shadow_medium != -1) {
+            const DMedium &med = sc.media[shadow_medium];
+            const f3 majorant = get_majorant(med, p, dir_light, (1.0f - sc.eps) * dist_to_light);
+            const float u = vrnd(rng);
+            const int channel = (int)(u * 3.0f) < 0 ? 0 : ((int)(u * 3.0f) > 2 ? 2 : (int)(u * 3.0f));
+            float accum_t = 0.0f; int iteration = 0;
+            for (;;) {
+                if (vget3(majorant, channel) <= 0.0f) break;
+                if (iteration >= sc.max_null_collisions) break;
+                const float tt = -logf(1.0f - vrnd(rng)) / vget3(majorant, channel);
+                const float dt = next_t - accum_t;
+                accum_t = fminf(accum_t + tt, next_t);
+                if (tt < dt) {
+                    f3 ss, sa; get_sigmas(sc, med, p + dir_light * accum_t, ss, sa);
+                    const f3 ratio = vdiv3(ss + sa, majorant), one_minus = mk3(1, 1, 1) - ratio;
+                    const f3 e = vexp3_scaled(-(majorant * tt));
+                    const float mx = max3(majorant);
+                    T = T * (e * (majorant * one_minus) / mx);
+                    p_trans_nee = p_trans_nee * (e * majorant / mx);
+                    p_trans_dir = p_trans_dir * (e * majorant * one_minus / mx);
+                    if (max3(T) <= 0.0f) break;
+                } else {
+                    const f3 e = vexp3_scaled(-(majorant * dt));
+                    T = T * e; p_trans_nee = p_trans_nee * e; p_trans_dir = p_trans_dir * e;
+                    break;
+                }
+                iteration++;
+            }
+        }
+        if (!hit) break;
+        if (sv.material_id >= 0) return mk3(0, 0, 0);
+        shadow_bounces++;
+        if (sc.max_depth != -1 && bounces + shadow_bounces >= sc.max_depth) return mk3(0, 0, 0);
+        shadow_medium = update_medium(sc, sv, dir_light, shadow_medium);
+        p = p + dir_light * next_t;
+    }
+    if (!(max3(T) > 0.0f)) return mk3(0, 0, 0);
+    const f3 Le = light_emission(sc, Lt, -dir_light, pl.normal);
+    const f3 dpl = p_origin - p_prime;
+    const float jacobian = fmaxf(-dot(dir_light, pl.normal), 0.0f) / dot(dpl, dpl);
+    const f3 pdf_nee = p_trans_nee * (Lt.pmf * pdf_point_on_light(sc, Lt, pl.position, pl.normal, p_origin));
+    f3 f, pdf_dir;
+    if (is_surface) {
+        float pdf_bsdf;
+        bsdf_eval_pdf(sc, sc.materials[vertex.material_id], dir_view, dir_light, vertex, f, pdf_bsdf);
+        if (pdf_bsdf <= 0.0f) return mk3(0, 0, 0);
+        pdf_dir = p_trans_dir * (pdf_bsdf * jacobian);
+    } else {
+        const DMedium &med = sc.media[current_medium];
+        (void)vrnd(rng); (void)vrnd(rng);   // phase_uv, drawn and never used (vol_path_tracing.h:475)
+        const float ph = phase_eval(med, dir_view, dir_light);
+        f = mk3(ph, ph, ph);
+        pdf_dir = p_trans_dir * (ph * jacobian);
+    }
+    const f3 contrib = T * f * Le * (jacobian / vavg3(pdf_nee));
+    const f3 n2 = pdf_nee * pdf_nee, d2 = pdf_dir * pdf_dir;
+    return contrib * vdiv3(n2, n2 + d2);
+}
+
+// vol_path_tracing (vol_path_tracing.h:503-869); see oracle/lj_oracle.cpp for the list of reference quirks kept
+template <class Tracer>
+LJ_HD f3 vol_path_sample(const DScene &sc, Tracer &tr, int x, int y, uint64_t stream, uint64_t seed, uint32_t &bounces_out) {
+    VolRng rng; rng.inc = pcg32_inc(stream); rng.state = pcg32_init(stream, seed);
+    const float jy = vrnd(rng), jx = vrnd(rng);
+    f3 org = ld3(sc.cam.org), dir = camera_primary_dir(sc.cam, x, y, jx, jy);
+    float spread = 0.0f;   // RayDifferential{0, 0}: only `spread` ever changes (ray.h:45-66 with radius 0)
+    int current_medium = sc.cam_medium;
+    f3 throughput = mk3(1, 1, 1), radiance = mk3(0, 0, 0);
+    int bounces = 0;
+    float dir_pdf = 0.0f; f3 nee_p_cache = mk3(0, 0, 0);
+    f3 multi_trans_pdf = mk3(1, 1, 1);
+    float eta_scale = 1.0f;
+    bounces_out = 0;
+    for (;;) {
+        bool scatter = false;
+        float t, hu, hv; int gprim;
+        const bool hit = tr.closest(org, dir, sc.eps, INFINITY, t, hu, hv, gprim);
+        DVertex vertex;
+        float t_hit = INFINITY;
+        if (hit) { vertex = build_vertex(sc, org, dir, t, hu, hv, gprim, spread); t_hit = length(vertex.position - org); }
+        f3 transmittance = mk3(1, 1, 1), trans_dir_pdf = mk3(1, 1, 1), trans_nee_pdf = mk3(1, 1, 1);
+        if (current_medium != -1) {
+            const DMedium &med = sc.media[current_medium];
+            const f3 majorant = get_majorant(med, org, dir, INFINITY);
+            const float u = vrnd(rng);
+            const int channel = (int)(u * 3.0f) < 0 ? 0 : ((int)(u * 3.0f) > 2 ? 2 : (int)(u * 3.0f));
+            float accum_t = 0.0f; int iteration = 0;
+            for (;;) {
+                if (vget3(majorant, channel) <= 0.0f) break;
+                if (iteration >= sc.max_null_collisions) break;
+                const float tt = -logf(1.0f - vrnd(rng)) / vget3(majorant, channel);
+                const float dt = t_hit - accum_t;
+                accum_t = fminf(accum_t + tt, t_hit);
+                if (tt < dt) {
+                    const f3 p = org + dir * accum_t;
+                    f3 ss, sa; get_sigmas(sc, med, p, ss, sa);
+                    const f3 real_prob = vdiv3(ss + sa, majorant), one_minus = mk3(1, 1, 1) - real_prob;
+                    const f3 e = vexp3_scaled(-(majorant * tt));
+                    const float mx = max3(majorant);
+                    if (vrnd(rng) < vget3(real_prob, channel)) {
+                        scatter = true;
+                        transmittance = transmittance * (e / mx);
+                        trans_dir_pdf = trans_dir_pdf * (e * majorant * real_prob / mx);
+                        org = p;
+                        break;
+                    }
+                    transmittance = transmittance * (e * (majorant * one_minus) / mx);
+                    trans_dir_pdf = trans_dir_pdf * (e * majorant * one_minus / mx);
+                    trans_nee_pdf = trans_nee_pdf * (e * majorant / mx);
+                } else {
+                    const f3 e = vexp3_scaled(-(majorant * dt));
+                    transmittance = transmittance * e; trans_dir_pdf = trans_dir_pdf * e; trans_nee_pdf = trans_nee_pdf * e;
+                    org = vertex.position;
+                    break;
+                }
+                iteration++;
+            }
+            multi_trans_pdf = multi_trans_pdf * trans_dir_pdf;
+        } else {
+            if (hit) org = vertex.position;
+            else return mk3(0, 0, 0);
+        }
+        throughput = throughput * (transmittance / vavg3(trans_dir_pdf));
+        if (!scatter && hit && vertex.light_id >= 0) {
+            const DLight &EL = sc.lights[vertex.light_id];
+            const f3 Le = light_emission(sc, EL, -dir, vertex.gn);
+            if (bounces == 0) return radiance + throughput * Le;
+            const f3 pdf_nee = trans_nee_pdf * (EL.pmf * pdf_point_on_light(sc, EL, vertex.position, vertex.gn, nee_p_cache));
+            const f3 dv = nee_p_cache - vertex.position;
+            const float jacobian = fmaxf(-dot(-dir, vertex.gn), 0.0f) / dot(dv, dv);
+            const f3 pdf_phase = multi_trans_pdf * (dir_pdf * jacobian);
+            const f3 p2 = pdf_phase * pdf_phase, n2 = pdf_nee * pdf_nee;
+            radiance = radiance + throughput * Le * vdiv3(p2, p2 + n2);
+        }
+        if (!scatter && hit && vertex.material_id == -1) {
+            current_medium = update_medium(sc, vertex, dir, current_medium);
+            org = vertex.position;
+            bounces++;
+            continue;
+        }
+        if (bounces >= sc.max_depth - 1 && sc.max_depth != -1) break;
+        bounces_out++;
+        if (scatter && current_medium != -1) {
+            const DMedium &med = sc.media[current_medium];
+            f3 sigma_s, sigma_a; get_sigmas(sc, med, org, sigma_s, sigma_a);
+            const f3 nee = vol_nee(sc, tr, rng, org, current_medium, bounces, -dir, false, vertex);
+            radiance = radiance + throughput * sigma_s * nee;
+            if (max3(nee) > 0.0f) nee_p_cache = org;
+            const float r0 = vrnd(rng), r1 = vrnd(rng);
+            const f3 next_dir = phase_sample(med, -dir, r0, r1);
+            const float phase_pdf = phase_eval(med, -dir, next_dir);
+            throughput = throughput * sigma_s * (phase_pdf / phase_pdf);
+            dir = next_dir;
+            dir_pdf = phase_pdf;
+            multi_trans_pdf = mk3(1, 1, 1);
+        } else if (hit) {
+            const f3 nee = vol_nee(sc, tr, rng, org, current_medium, bounces, -dir, true, vertex);
+            radiance = radiance + throughput * nee;
+            if (max3(nee) > 0.0f) nee_p_cache = org;
+            const DMaterial &mat = sc.materials[vertex.material_id];
+            const f3 dir_view = -dir;
+            const float b0 = vrnd(rng), b1 = vrnd(rng), bw = vrnd(rng);
+            const BsdfSample bs = bsdf_sample(sc, mat, dir_view, vertex, b0, b1, bw);
+            if (!bs.valid) break;
+            dir = bs.dir_out;
+            if (bs.eta == 0.0f) spread = fmaxf(spread * (1.0f - bs.roughness) + 0.2f * bs.roughness, 0.0f);
+            else {
+                spread = fmaxf((spread / bs.eta) * (1.0f - bs.roughness) + 0.2f * bs.roughness, 0.0f);
+                eta_scale /= (bs.eta * bs.eta);
+                current_medium = update_medium(sc, vertex, dir, current_medium);
+            }
+            f3 f; float pdf_bsdf;
+            bsdf_eval_pdf(sc, mat, dir_view, bs.dir_out, vertex, f, pdf_bsdf);
+            throughput = throughput * (f / pdf_bsdf);
+        }
+        if (bounces >= sc.rr_depth) {
+            const float rr_prob = fminf(max3(throughput * (1.0f / eta_scale)), 0.95f);
+            if (vrnd(rng) > rr_prob) break;
+            throughput = throughput / rr_prob;
+        }
+        bounces++;
+    }
+    return radiance;
+}
+
+} // namespace ljd

@@ -13,6 +13,7 @@
 //   k_trace_rays             : batched intersect()/occluded() for the parity tests
 #include <hip/hip_runtime.h>
 #include "dshade.h"
+#include "dvol.h"
 #include "dtrace.h"
 
 namespace ljd {
@@ -494,6 +495,42 @@ __global__ void __launch_bounds__(kBlock) k_aux(DScene sc, const uint32_t *pixel
     }
 }
 
+// ---------------------------------------------------------------- volumetric path tracer (dvol.h)
+// One lane walks one camera sample's whole path; closest hits come from the same traversal steps the extend kernel uses.
+struct DevTracer {
+    const TreeView &tv;
+    __device__ __forceinline__ bool closest(f3 org, f3 dir, float tnear, float tfar, float &t, float &u, float &v, int &gprim) {
+        LaneTrav L;
+        L.ray.ox = org.x; L.ray.oy = org.y; L.ray.oz = org.z; L.ray.dx = dir.x; L.ray.dy = dir.y; L.ray.dz = dir.z;
+        trav_begin(L, tnear, tfar);
+        while (L.cur != kDone) {
+            while (L.cur >= 0 && L.cur != kDone) trav_node_step<false>(tv, L);
+            if (L.cur < 0) trav_leaf_step<false, true>(tv, L, false);
+        }
+        trav_finish(L);
+        if (L.best.gprim < 0) return false;
+        t = L.best.t; u = L.best.u; v = L.best.v; gprim = L.best.gprim;
+        return true;
+    }
+};
+
+__global__ void __launch_bounds__(kBlock) k_volpath(DScene sc, DPass pass, uint32_t n_samples, unsigned long long *bounce_counter, int stack, int lds_nodes, int lds_prims, int *spill) {
+    const TreeView tv = stage_tree(sc, stack, lds_nodes, lds_prims, spill, gridDim.x * kBlock, blockIdx.x * kBlock + threadIdx.x);
+    DevTracer tr{tv};
+    uint32_t bounces = 0;
+    for (uint32_t s = blockIdx.x * kBlock + threadIdx.x; s < n_samples; s += gridDim.x * kBlock) {
+        const uint32_t p = s / pass.spp, k = s - p * pass.spp;
+        const uint32_t pixel = pass.pixel_list[p];
+        uint32_t nb = 0;
+        const f3 rad = vol_path_sample(sc, tr, (int)(pixel % (uint32_t)sc.cam.width), (int)(pixel / (uint32_t)sc.cam.width), (uint64_t)pixel * pass.spp + k, pass.seed, nb);
+        float *o = pass.sample_rgb + 3ull * s;
+        o[0] = rad.x; o[1] = rad.y; o[2] = rad.z;
+        bounces += nb;
+    }
+    const uint32_t wb = wave_sum(bounces);
+    if ((threadIdx.x & 63) == 0 && wb) atomicAdd(bounce_counter, (unsigned long long)wb);
+}
+
 // ---------------------------------------------------------------- launchers (called from api_device.hip)
 // A traversal of a BVH4 with `depth` inner levels holds at most 3 * depth entries.  The first `stack` levels of every
 // lane's stack live in LDS (1 KiB per level and workgroup); deeper levels — rare — go to a global overflow buffer.
@@ -587,6 +624,9 @@ void launch_resolve(const DPass &pass, uint32_t n_pixels, float *rgb, hipStream_
 }
 void launch_aux(const DScene &sc, const uint32_t *pixel_list, uint32_t n_pixels, int integrator, float *rgb, const ExtendConfig &cfg, int *spill, int grid, hipStream_t s) {
     if (n_pixels) hipLaunchKernelGGL(k_aux, dim3(grid), dim3(kBlock), cfg.smem, s, sc, pixel_list, n_pixels, integrator, rgb, cfg.stack, cfg.lds_nodes, cfg.lds_prims, spill);
+}
+void launch_volpath(const DScene &sc, const DPass &pass, uint32_t n_samples, unsigned long long *bounce_counter, const ExtendConfig &cfg, int *spill, int grid, hipStream_t s) {
+    if (n_samples) hipLaunchKernelGGL(k_volpath, dim3(grid), dim3(kBlock), cfg.smem, s, sc, pass, n_samples, bounce_counter, cfg.stack, cfg.lds_nodes, cfg.lds_prims, spill);
 }
 void launch_trace_rays(const DScene &sc, const void *rays, long long n, void *hits, unsigned char *occ, const ExtendConfig &cfg, int *spill, int grid, hipStream_t s) {
     hipLaunchKernelGGL(k_trace_rays, dim3(grid), dim3(kBlock), cfg.smem, s, sc, (const RayIO *)rays, n, (HitIO *)hits, occ, cfg.stack, cfg.lds_nodes, cfg.lds_prims, spill);

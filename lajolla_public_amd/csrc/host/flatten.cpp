@@ -78,13 +78,43 @@ ljd::DScene FlatScene::host_view() const {
     s.envmap_light_id = envmap_light_id; s.max_depth = max_depth; s.rr_depth = rr_depth;
     s.eps = (float)shadow_epsilon;
     s.init_spread = 0.25f / (float)std::max(cam.width, cam.height);
+    s.media = media.data(); s.n_media = (int)media.size(); s.volume_data = volume_data.data(); s.shape_media = shape_media.data();
+    s.cam_medium = cam_medium; s.max_null_collisions = max_null_collisions;
     return s;
 }
 
 FlatScene flatten_scene(const LjSceneDesc &d) {
     FlatScene F;
-    if (d.options.integrator < LJ_INTEGRATOR_DEPTH || d.options.integrator > LJ_INTEGRATOR_PATH)
-        throw LjError(LJ_ERR_UNSUPPORTED, "the `path` integrator (path_tracing.h) and the auxiliary buffers (render.cpp:12-69) run on the device; integrator id " + std::to_string(d.options.integrator) + " (volpath) is not implemented");
+    if (d.options.integrator < LJ_INTEGRATOR_DEPTH || d.options.integrator > LJ_INTEGRATOR_VOLPATH)
+        throw LjError(LJ_ERR_UNSUPPORTED, "integrator id " + std::to_string(d.options.integrator) + " is not implemented");
+    const bool volumetric = d.options.integrator == LJ_INTEGRATOR_VOLPATH;
+    F.cam_medium = d.camera.medium_id; F.max_null_collisions = d.options.max_null_collisions; F.vol_path_version = d.options.vol_path_version;
+    // ---- participating media (only the volumetric integrator looks at them)
+    auto medium_ok = [&](int id) { return id >= -1 && id < d.n_media; };
+    if (!medium_ok(d.camera.medium_id)) throw LjError(LJ_ERR_INVALID_ARG, "camera references a missing medium");
+    for (int i = 0; i < d.n_media; i++) {
+        const LjMedium &m = d.media[i];
+        ljd::DMedium o{};
+        if (m.kind != LJ_MEDIUM_HOMOGENEOUS && m.kind != LJ_MEDIUM_HETEROGENEOUS) throw LjError(LJ_ERR_UNSUPPORTED, "medium kind " + std::to_string(m.kind) + " is not implemented");
+        if (m.phase_kind != LJ_PHASE_ISOTROPIC && m.phase_kind != LJ_PHASE_HG) throw LjError(LJ_ERR_UNSUPPORTED, "phase function kind " + std::to_string(m.phase_kind) + " is not implemented");
+        o.kind = m.kind; o.phase_kind = m.phase_kind; o.g = (float)m.g;
+        for (int k = 0; k < 3; k++) { o.sigma_a[k] = (float)m.sigma_a[k]; o.sigma_s[k] = (float)m.sigma_s[k]; }
+        auto conv = [&](const LjVolume &v) {
+            ljd::DVolume r{};
+            r.kind = v.kind; r.scale = (float)v.scale;
+            for (int k = 0; k < 3; k++) { r.res[k] = v.resolution[k]; r.value[k] = (float)v.value[k]; r.p_min[k] = (float)v.p_min[k]; r.p_max[k] = (float)v.p_max[k]; r.max_data[k] = (float)v.max_data[k]; }
+            if (m.kind == LJ_MEDIUM_HETEROGENEOUS && v.kind == LJ_VOLUME_GRID) {
+                if (!v.data || v.resolution[0] <= 0 || v.resolution[1] <= 0 || v.resolution[2] <= 0) throw LjError(LJ_ERR_INVALID_ARG, "grid volume without voxels");
+                const size_t n = (size_t)v.resolution[0] * v.resolution[1] * v.resolution[2] * 3;
+                r.offset = (int64_t)F.volume_data.size();
+                F.volume_data.insert(F.volume_data.end(), v.data, v.data + n);
+            }
+            return r;
+        };
+        o.albedo = conv(m.albedo); o.density = conv(m.density);
+        F.media.push_back(o);
+    }
+    if (F.volume_data.empty()) F.volume_data.push_back(0.0f);
     F.integrator = d.options.integrator; F.spp = d.options.samples_per_pixel; F.max_depth = d.options.max_depth; F.rr_depth = d.options.rr_depth;
     F.envmap_light_id = d.envmap_light_id;
     // ---- camera
@@ -119,7 +149,10 @@ FlatScene flatten_scene(const LjSceneDesc &d) {
             int kind = d.materials[sh.material_id].kind;
             if (kind < LJ_MAT_LAMBERTIAN || kind > LJ_MAT_DISNEYBSDF)
                 throw LjError(LJ_ERR_UNSUPPORTED, "material alternative " + std::to_string(kind) + " (material.h:102-110) is not implemented on the device");
-        } else throw LjError(LJ_ERR_INVALID_ARG, "shape " + std::to_string(si) + " has no material (the reference asserts material_id >= 0, path_tracing.h:165)");
+        } else if (!volumetric) throw LjError(LJ_ERR_INVALID_ARG, "shape " + std::to_string(si) + " has no material (the reference asserts material_id >= 0, path_tracing.h:165)");
+        // (a shape without a material is an index-matched medium boundary for the volumetric integrator, vol_path_tracing.h:702-712)
+        if (!medium_ok(sh.interior_medium_id) || !medium_ok(sh.exterior_medium_id)) throw LjError(LJ_ERR_INVALID_ARG, "shape references a missing medium");
+        F.shape_media.push_back(sh.interior_medium_id); F.shape_media.push_back(sh.exterior_medium_id);
         if (sh.kind == LJ_SHAPE_SPHERE) {
             ljd::DSphere ds; for (int k = 0; k < 3; k++) ds.center[k] = sh.position[k]; ds.radius = sh.radius;
             int slot = (int)F.spheres.size(); F.spheres.push_back(ds);

@@ -23,6 +23,10 @@ struct FlatScene {
     std::vector<ljd::DImage> images3, images1;
     std::vector<float> texels;
     std::vector<float> env_tables;
+    std::vector<ljd::DMedium> media;
+    std::vector<float> volume_data;
+    std::vector<int32_t> shape_media;
+    int cam_medium = -1, max_null_collisions = 1000, vol_path_version = 0;
     int envmap_light_id = -1, max_depth = -1, rr_depth = 5, spp = 4, integrator = LJ_INTEGRATOR_PATH;
     int bvh_depth = 0;
     int64_t n_triangles = 0, n_spheres = 0;

@@ -1489,7 +1489,7 @@ inline int update_medium(const OScene &s, const PathVertex &v, const Ray &ray, i
 // next_event_estimation_final (vol_path_tracing.h:299-494).  The reference dereferences an empty optional at :344
 // (`shadow_vertex = *shadow_vertex_`); every later use of that value is guarded by the optional, so it is skipped here.
 Spectrum vol_nee(const OScene &scene, pcg32_state &rng, Vector3 p, int current_medium, int bounces, const Vector3 &dir_view,
-                 bool is_surface, const PathVertex &vertex, Counters *cnt, int *status) {
+                 bool is_surface, const PathVertex &vertex, int max_depth, Counters *cnt, int *status) {
     Vector2 light_uv; light_uv.x = next_pcg32_real(rng); light_uv.y = next_pcg32_real(rng);
     Real light_w = next_pcg32_real(rng);
     Real shape_w = next_pcg32_real(rng);
@@ -1498,7 +1498,6 @@ Spectrum vol_nee(const OScene &scene, pcg32_state &rng, Vector3 p, int current_m
     Vector3 dir_light = normalize(pl.position - p);
     const Vector3 p_prime = pl.position, p_origin = p;
     const Real eps = shadow_epsilon(scene);
-    const int max_depth = scene.d.options.max_depth;
     int shadow_medium = current_medium, shadow_bounces = 0;
     Spectrum T{1, 1, 1}, p_trans_nee{1, 1, 1}, p_trans_dir{1, 1, 1};
     for (;;) {
@@ -1574,7 +1573,7 @@ Spectrum vol_nee(const OScene &scene, pcg32_state &rng, Vector3 p, int current_m
 // an emitter reached by phase / BSDF sampling is weighted with a geometry term of the wrong sign, i.e. zero for a
 // front-facing hit (:688-695); no pdf > 0 check after BSDF sampling (:836-841).  nee_p_cache is read before it is
 // first written (:520, uninitialised in the reference): zero here.
-Spectrum vol_path_tracing(const OScene &scene, int x, int y, pcg32_state &rng, Counters *cnt, int *status) {
+Spectrum vol_path_tracing(const OScene &scene, int x, int y, pcg32_state &rng, int max_depth_override, bool use_override, Counters *cnt, int *status) {
     const LjCamera &cam = scene.d.camera;
     const int w = cam.width, h = cam.height;
     Real jy = next_pcg32_real(rng);   // g++ evaluates the constructor arguments right to left
@@ -1584,6 +1583,7 @@ Spectrum vol_path_tracing(const OScene &scene, int x, int y, pcg32_state &rng, C
     RayDifferential ray_diff{0, 0};
     if (cnt) cnt->samples++;
     const LjRenderOptions &opt = scene.d.options;
+    const int max_depth = use_override ? max_depth_override : opt.max_depth;
     int current_medium = cam.medium_id;
     Spectrum throughput{1, 1, 1}, radiance{0, 0, 0};
     int bounces = 0;
@@ -1657,12 +1657,12 @@ Spectrum vol_path_tracing(const OScene &scene, int x, int y, pcg32_state &rng, C
             bounces++;
             continue;
         }
-        if (bounces >= opt.max_depth - 1 && opt.max_depth != -1) break;
+        if (bounces >= max_depth - 1 && max_depth != -1) break;
         if (cnt) cnt->bounces++;
         if (scatter && current_medium != -1) {
             const LjMedium &med = scene.d.media[current_medium];
             Vector3 sigma_s = get_sigma_s(med, ray.org);
-            Spectrum nee = vol_nee(scene, rng, ray.org, current_medium, bounces, -ray.dir, false, vertex, cnt, status);
+            Spectrum nee = vol_nee(scene, rng, ray.org, current_medium, bounces, -ray.dir, false, vertex, max_depth, cnt, status);
             radiance += vmul(vmul(throughput, sigma_s), nee);
             if (vmax(nee) > 0) nee_p_cache = ray.org;
             Vector2 phase_uv; phase_uv.x = next_pcg32_real(rng); phase_uv.y = next_pcg32_real(rng);
@@ -1673,7 +1673,7 @@ Spectrum vol_path_tracing(const OScene &scene, int x, int y, pcg32_state &rng, C
             dir_pdf = phase_pdf;
             multi_trans_pdf = {1, 1, 1};
         } else if (hit) {
-            Spectrum nee = vol_nee(scene, rng, ray.org, current_medium, bounces, -ray.dir, true, vertex, cnt, status);
+            Spectrum nee = vol_nee(scene, rng, ray.org, current_medium, bounces, -ray.dir, true, vertex, max_depth, cnt, status);
             radiance += vmul(throughput, nee);
             if (vmax(nee) > 0) nee_p_cache = ray.org;
             const LjMaterial &mat = scene.materials[vertex.material_id];
@@ -1950,7 +1950,7 @@ int oracle_render(void *sv, const OracleRenderArgs *a, double *rgb, double *per_
                 for (int sidx = 0; sidx < spp; sidx++) {
                     int st = 0;
                     if (a->rng_mode == 0) rng = init_pcg32(((uint64_t)y * w + x) * (uint64_t)spp + sidx, seed);
-                    Spectrum L = s->d.options.integrator == LJ_INTEGRATOR_VOLPATH ? vol_path_tracing(*s, x, y, rng, &cnt, &st)
+                    Spectrum L = s->d.options.integrator == LJ_INTEGRATOR_VOLPATH ? vol_path_tracing(*s, x, y, rng, a->max_depth, a->use_max_depth != 0, &cnt, &st)
                                                                                    : path_tracing(*s, x, y, rng, a->max_depth, a->use_max_depth != 0, &cnt, &st);
                     if (st) status.store(st);
                     radiance += L;

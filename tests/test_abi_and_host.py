@@ -105,7 +105,7 @@ def test_unsupported_variants_fail_loudly():
         Twin(hs)
     assert "not implemented" in str(e.value)
     hs = lj.parse_scene(scene_path("cbox"))
-    hs.desc.options.integrator = 6  # volpath
+    hs.desc.options.integrator = 7  # not an Integrator alternative
     with pytest.raises(RuntimeError) as e:
         Twin(hs)
     assert "integrator" in str(e.value)

@@ -156,7 +156,7 @@ def test_unsupported_variants_are_refused(ctx):
         lj.Scene(ctx, hs)
     assert e.value.code == _abi.LJ_ERR_UNSUPPORTED
     hs = lj.parse_scene(scene_path("cbox"))
-    hs.desc.options.integrator = 6   # volpath: outside the accelerated path
+    hs.desc.options.integrator = 7   # not an Integrator alternative
     with pytest.raises(lj.LajollaError) as e:
         lj.Scene(ctx, hs)
     assert e.value.code == _abi.LJ_ERR_UNSUPPORTED

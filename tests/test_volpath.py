@@ -1,0 +1,79 @@
+"""The volumetric path tracer (vol_path_tracing.h:503-869 with next_event_estimation_final :299-494).
+
+The reference's earlier versions (vol_path_tracing_1..5, selected by the scene's `version`) are special cases of the
+final one and are rendered with it.  Parity with the reference is statistical by SURVEY's own bar — it cannot be run here
+(Embree) and contains undefined behaviour — so the chain is: reference medium / phase / volume functions -> oracle (known
+answers, tests/test_oracle_golden.py) -> an analytic case -> device code against the oracle under identical pcg32 streams,
+where float and double walk the same path until a discrete decision flips."""
+import os
+
+import numpy as np
+import pytest
+
+import lajolla_public_amd as lj
+from lajolla_public_amd import _abi
+from helpers import Oracle, Twin, ROOT
+
+CASES = [("volpath_test1", (240, 240, 272, 272)), ("volpath_test3", (200, 200, 264, 264)), ("volpath_test5", (200, 200, 264, 264)),
+         ("volpath_test6", (200, 200, 264, 264)), ("vol_cbox_teapot", (200, 250, 264, 314)), ("hetvol", (350, 250, 414, 314)),
+         ("hetvol_colored", (350, 250, 414, 314))]
+
+
+def vol_scene(name):
+    return lj.parse_scene(os.path.join(ROOT, "scenes", "volpath_test", name + ".xml"))
+
+
+def check_samples(got, ref):
+    assert np.isfinite(got).all() == np.isfinite(ref).all()
+    fin = np.isfinite(ref).all(axis=-1) & np.isfinite(got).all(axis=-1)
+    g, r = got[fin].astype(float), ref[fin]
+    rel = np.abs(g - r).max(axis=-1) / np.maximum(np.abs(r).max(axis=-1), 1e-3)
+    assert np.median(rel) < 2e-6
+    assert (rel > 1e-3).mean() < 0.03
+    assert abs(g.mean() / r.mean() - 1) < 2e-3
+    d = (np.minimum(g, 8.0) - np.minimum(r, 8.0)).sum(axis=-1)
+    # zero-mean differences, up to 3e-4 of the total: a point sampled in float on the silhouette of a sphere light can
+    # fall just behind the horizon and be shadowed by the light itself, where the double-precision point is just visible
+    # (its contribution is small — the light-side cosine vanishes there — but it is always lost, never gained)
+    assert abs(d.sum()) <= 4.0 * np.sqrt((d * d).sum()) + 3e-4 * np.abs(r).sum() + 1e-6
+
+
+def test_absorbing_medium_matches_the_closed_form():
+    """volpath_test1: an emitter seen through a purely absorbing homogeneous medium, maxDepth 1 -> L = exp(-sigma_a d) Le."""
+    hs = vol_scene("volpath_test1")
+    o = Oracle(hs)
+    crop = (252, 252, 260, 260)
+    rc, img, _, _ = o.render(spp=2048, crop=crop)
+    assert rc == 0
+    mean = img[252:260, 252:260].mean(axis=(0, 1))
+    m = hs.desc.media[0]
+    le = np.array(list(hs.desc.lights[0].intensity))
+    expect = np.exp(-np.array(list(m.sigma_a)) * 2.0) * le    # camera at z = -3, unit sphere at the origin
+    assert np.allclose(mean, expect, rtol=2e-2)
+
+
+@pytest.mark.parametrize("name,crop", CASES)
+def test_device_code_follows_the_oracle(name, crop):
+    hs = vol_scene(name)
+    o, tw = Oracle(hs), Twin(hs)
+    rc, _, ps, st = o.render(spp=8, crop=crop, per_sample=True)
+    assert rc == 0
+    pt, bounces = tw.render_samples(crop, 8)
+    check_samples(pt, ps)
+    assert abs(bounces - st.bounces) <= 0.02 * max(st.bounces, 1) + 8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,crop", CASES)
+def test_gpu_follows_the_oracle(name, crop):
+    hs = vol_scene(name)
+    sc, o = lj.Scene(lj.Context(0), hs), Oracle(hs)
+    rc, _, ps, st = o.render(spp=8, crop=crop, per_sample=True)
+    pg = lj.render_samples(sc, crop, spp=8)
+    check_samples(pg, ps)
+    # a frame: finite, deterministic, sharded ranks add up, mean radiance agrees with an oracle frame at the same spp
+    a = lj.render(sc, spp=2)
+    same = bool(np.array_equal(a, lj.render(sc, spp=2))) and bool(np.array_equal(a, lj.render(sc, spp=2, rank=0, world_size=2) + lj.render(sc, spp=2, rank=1, world_size=2)))
+    assert same and bool(np.isfinite(a).all())
+    rc, ref, _, _ = o.render(spp=2)
+    assert abs(a.mean() / ref.mean() - 1) < 2e-3

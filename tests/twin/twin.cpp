@@ -5,6 +5,7 @@
 // any GPU minute is spent.  This library is built only by the test suite, lives under tests/, is never loaded by
 // the product and is not a fallback: lajolla_public_amd has no code path that reaches it.
 #include "../../lajolla_public_amd/csrc/device/dshade.h"
+#include "../../lajolla_public_amd/csrc/device/dvol.h"
 #include "../../lajolla_public_amd/csrc/device/dtrace.h"
 #include "../../lajolla_public_amd/csrc/host/flatten.h"
 #include <cstdio>
@@ -56,6 +57,19 @@ void extend_one(const DScene &sc, PathState &ps) {
 
 struct Twin { lj::FlatScene flat; DScene view; };
 
+// what k_volpath's tracer does: one closest-hit query over the BVH
+struct HostTracer {
+    const DScene &sc;
+    bool closest(f3 org, f3 dir, float tnear, float tfar, float &t, float &u, float &v, int &gprim) {
+        HostMem mem(sc);
+        RayF ray; ray.ox = org.x; ray.oy = org.y; ray.oz = org.z; ray.dx = dir.x; ray.dy = dir.y; ray.dz = dir.z; ray.tnear = tnear; ray.tfar = tfar;
+        HitRec h;
+        if (!traverse<false>(mem, ray, h)) return false;
+        t = h.t; u = h.u; v = h.v; gprim = h.gprim;
+        return true;
+    }
+};
+
 } // namespace
 
 extern "C" {
@@ -100,6 +114,15 @@ void twin_render_samples(void *tv, int spp, int max_depth, int use_max_depth, ui
     auto worker = [&](int tid) {
         ShadeCounters cnt{};
         for (uint64_t s = tid; s < total; s += n_threads) {
+            if (t->flat.integrator == LJ_INTEGRATOR_VOLPATH) {   // k_volpath: the whole path in one go
+                HostTracer tr{sc};
+                const uint32_t pixel = pixels[s / spp];
+                uint32_t nb = 0;
+                const f3 r = vol_path_sample(sc, tr, (int)(pixel % (uint32_t)w), (int)(pixel / (uint32_t)w), (uint64_t)pixel * spp + (s % spp), pass.seed, nb);
+                out[3 * s] = r.x; out[3 * s + 1] = r.y; out[3 * s + 2] = r.z;
+                cnt.bounces += nb;
+                continue;
+            }
             PathState ps;
             generate_path(sc, pass, (uint32_t)s, ps);
             for (int step = 0; step < 100000; step++) {
