@@ -71,6 +71,7 @@ struct lj_scene {
     lj_context *ctx = nullptr;
     lj::FlatScene flat;  // host copy (tables for lj_scene_info; arrays already uploaded)
     DevBuf nodes, leaf_prims, prims, spheres, materials, lights, light_cdf, light_tris, light_tri_cdf, images3, images1, texels, env_tables;
+    DevBuf media, volume_data, shape_media;
     ljd::DScene dscene{};
     ljd::ExtendConfig ecfg{};
     ljd::ShadeConfig scfg{};
@@ -423,12 +424,14 @@ int lj_scene_upload(lj_context *ctx, const LjSceneDesc *desc, lj_scene **out) {
         upload(sc->materials, F.materials, s); upload(sc->lights, F.lights, s); upload(sc->light_cdf, F.light_cdf, s);
         upload(sc->light_tris, F.light_tris, s); upload(sc->light_tri_cdf, F.light_tri_cdf, s);
         upload(sc->images3, F.images3, s); upload(sc->images1, F.images1, s); upload(sc->texels, F.texels, s); upload(sc->env_tables, F.env_tables, s);
+        upload(sc->media, F.media, s); upload(sc->volume_data, F.volume_data, s); upload(sc->shape_media, F.shape_media, s);
         HIP_CHECK(hipStreamSynchronize(s));
         ljd::DScene d = F.host_view();
         d.nodes = (const ljd::DNode4 *)sc->nodes.p; d.leaf_prims = (const ljd::DPrim *)sc->leaf_prims.p; d.prims = (const ljd::DPrimShade *)sc->prims.p;
         d.spheres = (const ljd::DSphere *)sc->spheres.p; d.materials = (const ljd::DMaterial *)sc->materials.p; d.lights = (const ljd::DLight *)sc->lights.p;
         d.light_cdf = (const float *)sc->light_cdf.p; d.light_tris = (const ljd::DLightTri *)sc->light_tris.p; d.light_tri_cdf = (const float *)sc->light_tri_cdf.p;
         d.images3 = (const ljd::DImage *)sc->images3.p; d.images1 = (const ljd::DImage *)sc->images1.p; d.texels = (const float *)sc->texels.p; d.env_tables = (const float *)sc->env_tables.p;
+        d.media = (const ljd::DMedium *)sc->media.p; d.volume_data = (const float *)sc->volume_data.p; d.shape_media = (const int32_t *)sc->shape_media.p;
         sc->dscene = d;
         if (F.bvh_depth > ljd::max_stack_depth())
             throw LjError(LJ_ERR_INTERNAL, "BVH depth " + std::to_string(F.bvh_depth) + " exceeds the traversal stack");

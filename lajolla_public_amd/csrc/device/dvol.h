@@ -111,7 +111,9 @@ LJ_HD f3 vol_nee(const DScene &sc, Tracer &tr, VolRng &rng, f3 p, int current_me
     const f3 p_prime = pl.position, p_origin = p;
     int shadow_medium = current_medium, shadow_bounces = 0;
     f3 T = mk3(1, 1, 1), p_trans_nee = mk3(1, 1, 1), p_trans_dir = mk3(1, 1, 1);
-    for (;;) {
+    // (every pass moves p at least eps along the ray, so the walk ends; the cap only bounds a degenerate scene)
+    for (int segment = 0;; segment++) {
+        if (segment >= 4096) return mk3(0, 0, 0);
         const float dist_to_light = length(p_prime - p);
         float t, hu, hv; int gprim;
         const bool hit = tr.closest(p, dir_light, sc.eps, (1.0f - sc.eps) * dist_to_light, t, hu, hv, gprim);
@@ -191,7 +193,8 @@ LJ_HD f3 vol_path_sample(const DScene &sc, Tracer &tr, int x, int y, uint64_t st
     f3 multi_trans_pdf = mk3(1, 1, 1);
     float eta_scale = 1.0f;
     bounces_out = 0;
-    for (;;) {
+    // (Russian roulette ends a path with probability >= 5 % per iteration past rr_depth; the cap bounds rr_depth = huge)
+    for (int guard = 0; guard < 65536; guard++) {
         bool scatter = false;
         float t, hu, hv; int gprim;
         const bool hit = tr.closest(org, dir, sc.eps, INFINITY, t, hu, hv, gprim);

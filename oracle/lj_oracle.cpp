@@ -1408,6 +1408,12 @@ OScene *scene_create(const LjSceneDesc *d) {
 
 // =================================================================== C entry points for the tests (ctypes)
 // ------------------------------------------------------------------ participating media
+// lajolla.h:63-71: the reference's own min / max templates.  With a NaN first argument they return the SECOND one, which
+// is what keeps Russian roulette alive (probability 0.95) when a throughput has degenerated to 0 / 0 after a chain of
+// null collisions underflowed both the transmittance and its pdf — std::min would return the NaN and never terminate.
+inline Real ref_min(Real a, Real b) { return a < b ? a : b; }
+inline Real ref_max(Real a, Real b) { return a > b ? a : b; }
+inline Real ref_vmax(const Vector3 &v) { return ref_max(ref_max(v.x, v.y), v.z); }
 inline Vector3 vmul(const Vector3 &a, const Vector3 &b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
 inline Vector3 vdiv(const Vector3 &a, const Vector3 &b) { return {a.x / b.x, a.y / b.y, a.z / b.z}; }
 inline Vector3 vexp(const Vector3 &a) { return {std::exp(a.x), std::exp(a.y), std::exp(a.z)}; }
@@ -1695,7 +1701,7 @@ Spectrum vol_path_tracing(const OScene &scene, int x, int y, pcg32_state &rng, i
             throughput = vmul(throughput, f / pdf_bsdf);
         }
         if (bounces >= opt.rr_depth) {
-            Real rr_prob = std::min(vmax((1 / eta_scale) * throughput), Real(0.95));
+            Real rr_prob = ref_min(ref_vmax((1 / eta_scale) * throughput), Real(0.95));
             if (next_pcg32_real(rng) > rr_prob) break;
             throughput = throughput / rr_prob;
         }
