@@ -22,6 +22,8 @@ int max_stack_depth();
 void launch_extend(const DScene &sc, const DQueue &q, const DBlockState *blocks, uint32_t grid, uint32_t seg, uint32_t *work, const uint32_t *chunk_list, uint32_t parity, const ExtendConfig &cfg, int *spill, unsigned long long *stats, hipStream_t s);
 void launch_shade(const DScene &sc, const DPass &pass, const DQueue &q, DBlockState *blocks, uint32_t n_blocks, uint32_t seg, const ShadeConfig &cfg, uint32_t *work, uint32_t *chunk_list, uint32_t parity, uint32_t extend_waves, hipStream_t s);
 void launch_resolve(const DPass &pass, uint32_t n_pixels, float *rgb, hipStream_t s);
+size_t tail_smem(const ExtendConfig &ecfg, const ShadeConfig &scfg);
+void launch_tail(const DScene &sc, const DPass &pass, const DQueue &q, DBlockState *blocks, uint32_t n_blocks, uint32_t seg, const ExtendConfig &ecfg, const ShadeConfig &scfg, int *spill, hipStream_t s);
 void launch_aux(const DScene &sc, const uint32_t *pixel_list, uint32_t n_pixels, int integrator, float *rgb, const ExtendConfig &cfg, int *spill, int grid, hipStream_t s);
 void launch_volpath(const DScene &sc, const DPass &pass, uint32_t n_samples, unsigned long long *bounce_counter, const ExtendConfig &cfg, int *spill, int grid, hipStream_t s);
 void launch_trace_rays(const DScene &sc, const void *rays, long long n, void *hits, unsigned char *occ, const ExtendConfig &cfg, int *spill, int grid, hipStream_t s);
@@ -237,7 +239,12 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
     if (const char *e = getenv("LJ_TUNE_EXTEND_BLOCKS_PER_CU")) ext_per_cu = (uint32_t)std::max(1, atoi(e));
     const uint32_t lane_chunks = lane_slots / 256u;
     const uint32_t ext_grid = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)ctx->n_cus * ext_per_cu, (lane_chunks + 3) / 4));
-    int *spill_base = ensure_spill(ctx, sc->ecfg.spill_levels, ext_grid * n_lanes);
+    // (the fused tail launches one workgroup per segment, so its overflow stacks are sized for the shade grid)
+    const bool use_tail = !timing && !xstats && ljd::tail_smem(sc->ecfg, sc->scfg) > 0 && !(getenv("LJ_TUNE_TAIL") && atoi(getenv("LJ_TUNE_TAIL")) == 0);
+    uint64_t tail_num = 1, tail_den = 4;   // fuse once fewer than tail_num / tail_den of the slots hold a path
+    if (const char *e = getenv("LJ_TUNE_TAIL_FRAC")) { tail_num = (uint64_t)std::max(1, atoi(e)); tail_den = 16; }
+    const uint32_t spill_grid = std::max<uint32_t>(ext_grid, use_tail ? lane_blocks : 0u);
+    int *spill_base = ensure_spill(ctx, sc->ecfg.spill_levels, spill_grid * n_lanes);
     // per lane: work[0] = the extend kernel's draw counter, work[1 + parity] = number of listed chunks; two chunk lists, used
     // alternately, so that a shade launch can append to one while nothing reads it
     if (!ctx->chunk_counter.p) ctx->chunk_counter.alloc(512);
@@ -245,7 +252,7 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
     const ljd::DQueue q_all = carve_queue(ctx->queue_mem.p, ctx->queue_capacity);
     struct Lane {
         hipStream_t stream; ljd::DQueue q; ljd::DBlockState *dblocks; ljd::DBlockState *hblocks;
-        uint32_t *work; uint32_t *lists[2]; uint32_t parity; int *spill; bool done; int batch;
+        uint32_t *work; uint32_t *lists[2]; uint32_t parity; int *spill; int *spill_tail; bool done; int batch;
     } lanes[4];
     for (uint32_t l = 0; l < n_lanes; l++) {
         Lane &L = lanes[l];
@@ -255,7 +262,8 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
         L.dblocks = (ljd::DBlockState *)ctx->blocks.p + (size_t)l * lane_blocks; L.hblocks = ctx->blocks_host + (size_t)l * lane_blocks;
         L.work = (uint32_t *)ctx->chunk_counter.p + 32 * l;
         L.lists[0] = (uint32_t *)ctx->chunk_list.p + (size_t)l * 2 * lane_chunks; L.lists[1] = L.lists[0] + lane_chunks;
-        L.spill = spill_base ? spill_base + (size_t)l * sc->ecfg.spill_levels * ext_grid * 256 : nullptr;
+        L.spill = spill_base ? spill_base + (size_t)l * sc->ecfg.spill_levels * spill_grid * 256 : nullptr;
+        L.spill_tail = L.spill;
     }
     if (ctx->sample_rgb.bytes < pass_samples_max * 12) ctx->sample_rgb.alloc(pass_samples_max * 12);
     if (ctx->pixel_list.bytes < n_pix * 4) ctx->pixel_list.alloc(n_pix * 4);
@@ -311,6 +319,17 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
                     // the long tail (a few deep paths left): launches are nearly empty, so look less often
                     L.batch = alive * 64ull < (uint64_t)lane_slots ? 16 : 8;
                     if (L.done) continue;
+                    // ... or not at all: once every camera sample has been started and the segments are mostly empty, the
+                    // rest of the lane's paths finish inside one fused launch (k_tail)
+                    uint64_t to_start = 0;
+                    for (uint32_t b = 0; b < lane_blocks; b++) to_start += L.hblocks[b].end_sample - L.hblocks[b].next_sample;
+                    if (use_tail && to_start == 0 && alive * tail_den < (uint64_t)lane_slots * tail_num) {
+                        ljd::launch_tail(ds, pass, L.q, L.dblocks, lane_blocks, seg, sc->ecfg, sc->scfg, L.spill_tail, L.stream);
+                        HIP_CHECK(hipGetLastError());
+                        HIP_CHECK(hipMemcpyAsync(L.hblocks, L.dblocks, sizeof(ljd::DBlockState) * lane_blocks, hipMemcpyDeviceToHost, L.stream));
+                        pending[l] = true; any = true;
+                        continue;
+                    }
                 }
                 any = true;
                 for (int b = 0; b < L.batch; b++) {

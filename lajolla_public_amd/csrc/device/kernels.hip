@@ -347,39 +347,12 @@ __device__ __forceinline__ void lds_copy16(void *dst, const void *src, uint32_t 
     for (uint32_t i = threadIdx.x; i < bytes / 16; i += kBlock) d4[i] = s4[i];
 }
 
-// Feature sets the shade kernel is compiled for, smallest first (DESIGN.md §4.2).  kinds: bit k = Material alternative k.
-using FeatLambert = ShadeFeat<0x001u, false, false, false>;      // constant-colour diffuse surfaces, mesh lights (cbox)
-using FeatLambertTex = ShadeFeat<0x001u, true, false, true>;     // + image / checker textures, sphere lights (sponza)
-using FeatClassic = ShadeFeat<0x007u, true, true, true>;         // diffuse, roughplastic, roughdielectric + everything else
-#ifndef LJ_LAMBERT_OCC
-#define LJ_LAMBERT_OCC 4
-#endif
-template <class Ft> struct ShadeOccupancy { static constexpr int waves = 4; };
-template <> struct ShadeOccupancy<FeatLambert> { static constexpr int waves = LJ_LAMBERT_OCC; };
-
+// Shade the `count` live paths at the front of one segment chunk by chunk; survivors are compacted to the front, in
+// order (stable).  Returns the number of survivors (identical in every thread).  s_wcnt: 2 x (kBlock / 64) words of LDS.
 template <class Ft>
-__global__ void __launch_bounds__(kBlock, ShadeOccupancy<Ft>::waves) k_shade(DScene sc, DPass pass, DQueue q, DBlockState *blocks, uint32_t seg, ShadeStage stg, uint32_t *work, uint32_t *chunk_list, uint32_t parity, uint32_t extend_waves) {
-    __shared__ uint32_t s_list_base;
-    if (blockIdx.x == 0 && threadIdx.x == 0) work[0] = extend_waves;   // the extend launch that follows draws list entries beyond its own waves from it
-    __shared__ uint32_t s_wcnt[2][kBlock / 64];
-    __shared__ unsigned long long s_cnt[5];
-    {
-        char *p = (char *)lj_smem;
-        if (stg.stage_prims) { lds_copy16(p, sc.prims, stg.prims_bytes); sc.prims = (const DPrimShade *)p; p += stg.prims_bytes; }
-        lds_copy16(p, sc.materials, stg.materials_bytes); sc.materials = (const DMaterial *)p; p += stg.materials_bytes;
-        lds_copy16(p, sc.lights, stg.lights_bytes); sc.lights = (const DLight *)p; p += stg.lights_bytes;
-        lds_copy16(p, sc.light_cdf, stg.light_cdf_bytes); sc.light_cdf = (const float *)p; p += stg.light_cdf_bytes;
-        lds_copy16(p, sc.light_tris, stg.light_tris_bytes); sc.light_tris = (const DLightTri *)p; p += stg.light_tris_bytes;
-        lds_copy16(p, sc.light_tri_cdf, stg.light_tri_cdf_bytes); sc.light_tri_cdf = (const float *)p;
-    }
-    DBlockState &bs = blocks[blockIdx.x];
-    const uint32_t count = bs.count, next_sample = bs.next_sample, end_sample = bs.end_sample;
-    if (threadIdx.x < 5) s_cnt[threadIdx.x] = 0ull;
-    __syncthreads();
-    ShadeCounters cnt; cnt.bounces = cnt.closest = cnt.shadow = cnt.done = 0;
-    const uint32_t base = blockIdx.x * seg, wave = threadIdx.x >> 6;
+__device__ __forceinline__ uint32_t shade_compact_segment(const DScene &sc, const DPass &pass, const DQueue &q, uint32_t base, uint32_t count, ShadeCounters &cnt, uint32_t (*s_wcnt)[kBlock / 64]) {
+    const uint32_t wave = threadIdx.x >> 6;
     uint32_t out = 0;  // survivors written so far (identical in every thread)
-    // ---- shade the live front of the segment chunk by chunk; survivors are compacted to the front, in order
     for (uint32_t c0 = 0, it = 0; c0 < count; c0 += kBlock, it++) {
         const uint32_t j = c0 + threadIdx.x;
         bool alive = false;
@@ -404,6 +377,45 @@ __global__ void __launch_bounds__(kBlock, ShadeOccupancy<Ft>::waves) k_shade(DSc
         if (alive) q_store(q, base + out + before + rank, ps);
         out += total;
     }
+    return out;
+}
+
+// LDS staging of the shading tables at byte offset `at` of the dynamic segment; rewrites the pointers of `sc`
+__device__ __forceinline__ void stage_shade_tables(DScene &sc, const ShadeStage &stg, uint32_t at) {
+    char *p = (char *)lj_smem + at;
+    if (stg.stage_prims) { lds_copy16(p, sc.prims, stg.prims_bytes); sc.prims = (const DPrimShade *)p; p += stg.prims_bytes; }
+    lds_copy16(p, sc.materials, stg.materials_bytes); sc.materials = (const DMaterial *)p; p += stg.materials_bytes;
+    lds_copy16(p, sc.lights, stg.lights_bytes); sc.lights = (const DLight *)p; p += stg.lights_bytes;
+    lds_copy16(p, sc.light_cdf, stg.light_cdf_bytes); sc.light_cdf = (const float *)p; p += stg.light_cdf_bytes;
+    lds_copy16(p, sc.light_tris, stg.light_tris_bytes); sc.light_tris = (const DLightTri *)p; p += stg.light_tris_bytes;
+    lds_copy16(p, sc.light_tri_cdf, stg.light_tri_cdf_bytes); sc.light_tri_cdf = (const float *)p;
+}
+
+// Feature sets the shade kernel is compiled for, smallest first (DESIGN.md §4.2).  kinds: bit k = Material alternative k.
+using FeatLambert = ShadeFeat<0x001u, false, false, false>;      // constant-colour diffuse surfaces, mesh lights (cbox)
+using FeatLambertTex = ShadeFeat<0x001u, true, false, true>;     // + image / checker textures, sphere lights (sponza)
+using FeatClassic = ShadeFeat<0x007u, true, true, true>;         // diffuse, roughplastic, roughdielectric + everything else
+#ifndef LJ_LAMBERT_OCC
+#define LJ_LAMBERT_OCC 4
+#endif
+template <class Ft> struct ShadeOccupancy { static constexpr int waves = 4; };
+template <> struct ShadeOccupancy<FeatLambert> { static constexpr int waves = LJ_LAMBERT_OCC; };
+
+template <class Ft>
+__global__ void __launch_bounds__(kBlock, ShadeOccupancy<Ft>::waves) k_shade(DScene sc, DPass pass, DQueue q, DBlockState *blocks, uint32_t seg, ShadeStage stg, uint32_t *work, uint32_t *chunk_list, uint32_t parity, uint32_t extend_waves) {
+    __shared__ uint32_t s_list_base;
+    if (blockIdx.x == 0 && threadIdx.x == 0) work[0] = extend_waves;   // the extend launch that follows draws list entries beyond its own waves from it
+    __shared__ uint32_t s_wcnt[2][kBlock / 64];
+    __shared__ unsigned long long s_cnt[5];
+    stage_shade_tables(sc, stg, 0u);
+    DBlockState &bs = blocks[blockIdx.x];
+    const uint32_t count = bs.count, next_sample = bs.next_sample, end_sample = bs.end_sample;
+    if (threadIdx.x < 5) s_cnt[threadIdx.x] = 0ull;
+    __syncthreads();
+    ShadeCounters cnt; cnt.bounces = cnt.closest = cnt.shadow = cnt.done = 0;
+    const uint32_t base = blockIdx.x * seg;
+    // ---- shade the live front of the segment chunk by chunk; survivors are compacted to the front, in order
+    const uint32_t out = shade_compact_segment<Ft>(sc, pass, q, base, count, cnt, s_wcnt);
     // ---- refill the rest of the segment with the workgroup's next camera samples (path_tracing.h:10-14)
     const uint32_t left = end_sample - next_sample, room = seg - out;
     const uint32_t n_new = left < room ? left : room;
@@ -427,6 +439,76 @@ __global__ void __launch_bounds__(kBlock, ShadeOccupancy<Ft>::waves) k_shade(DSc
         bs.next_sample = next_sample + n_new;
         bs.count = out + n_new;
         bs.bounce_iterations += s_cnt[0]; bs.rays_closest += s_cnt[1]; bs.rays_shadow += s_cnt[2]; bs.samples_done += s_cnt[3]; bs.path_steps += count;
+    }
+}
+
+// ---------------------------------------------------------------- the tail of a render, fused
+// When no camera sample is left to start and only the long-lived paths remain, a launch pair per bounce is mostly launch
+// overhead (~10 us each, tens of bounces).  A workgroup's segment is independent of every other one, so the rest of the
+// render runs inside ONE launch: each workgroup alternates "trace my live paths" and "shade + compact my segment" until
+// its segment is empty.  Per-sample values are the same as with separate launches, bit for bit.
+template <class Ft>
+__global__ void __launch_bounds__(kBlock, 2) k_tail(DScene sc, DPass pass, DQueue q, DBlockState *blocks, uint32_t seg, ShadeStage stg, uint32_t shade_lds_at,
+                                                    int stack, int lds_nodes, int lds_prims, int *spill) {
+    __shared__ uint32_t s_wcnt[2][kBlock / 64];
+    const TreeView tv = stage_tree(sc, stack, lds_nodes, lds_prims, spill, gridDim.x * kBlock, blockIdx.x * kBlock + threadIdx.x);
+    DScene ssc = sc;                       // the shading view of the scene: tables in LDS
+    stage_shade_tables(ssc, stg, shade_lds_at);
+    __syncthreads();
+    DBlockState &bs = blocks[blockIdx.x];
+    uint32_t count = bs.count;
+    const uint32_t base = blockIdx.x * seg;
+    ShadeCounters cnt; cnt.bounces = cnt.closest = cnt.shadow = cnt.done = 0;
+    unsigned long long path_steps = 0;
+    for (int guard = 0; guard < (1 << 16) && count > 0; guard++) {
+        // ---- extend: one lane per path, shadow ray (any hit) then extension ray (closest hit)
+        for (uint32_t i = threadIdx.x; i < count; i += kBlock) {
+            const uint32_t path = base + i;
+            const Rec4 ro = q.ro[path], rd = q.rd[path];
+            const uint32_t flags = f2u(rd.w);
+            LaneTrav L;
+            L.ray.ox = ro.x; L.ray.oy = ro.y; L.ray.oz = ro.z;
+            uint32_t vis = 0;
+            if (ro.w > 0.0f) {
+                const Rec4 rs = q.rs[path];
+                L.ray.dx = rs.x; L.ray.dy = rs.y; L.ray.dz = rs.z;
+                trav_begin(L, sc.eps, ro.w);
+                while (L.cur != kDone) {
+                    while (L.cur >= 0 && L.cur != kDone) trav_node_step<false>(tv, L);
+                    if (L.cur < 0) trav_leaf_step<false, true>(tv, L, true);
+                }
+                vis = (L.best.gprim < 0) ? (uint32_t)HIT_VIS_BIT : 0u;
+            }
+            if (!(flags & PF_NO_EXT)) {
+                L.ray.dx = rd.x; L.ray.dy = rd.y; L.ray.dz = rd.z;
+                trav_begin(L, ((flags & 0xffffu) == 2u) ? 0.0f : sc.eps, INFINITY);
+                while (L.cur != kDone) {
+                    while (L.cur >= 0 && L.cur != kDone) trav_node_step<false>(tv, L);
+                    if (L.cur < 0) trav_leaf_step<false, true>(tv, L, false);
+                }
+                trav_finish(L);
+                const bool hit = L.best.gprim >= 0;
+                q.rh[path] = mk4(hit ? L.best.t : 0.0f, L.best.u, L.best.v, u2f(vis | (uint32_t)(L.best.gprim + 1)));
+            } else q.rh[path] = mk4(0.0f, 0.0f, 0.0f, u2f(vis));
+        }
+        __syncthreads();   // (workgroup-scope release/acquire of the records just written)
+        // ---- shade + compact
+        path_steps += count;
+        count = shade_compact_segment<Ft>(ssc, pass, q, base, count, cnt, s_wcnt);
+        __syncthreads();
+    }
+    __shared__ unsigned long long s_cnt[4];
+    if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0ull;
+    __syncthreads();
+    const uint32_t b = wave_sum(cnt.bounces), cl = wave_sum(cnt.closest), sh = wave_sum(cnt.shadow), dn = wave_sum(cnt.done);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&s_cnt[0], (unsigned long long)b); atomicAdd(&s_cnt[1], (unsigned long long)cl); atomicAdd(&s_cnt[2], (unsigned long long)sh);
+        atomicAdd(&s_cnt[3], (unsigned long long)dn);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        bs.count = count;
+        bs.bounce_iterations += s_cnt[0]; bs.rays_closest += s_cnt[1]; bs.rays_shadow += s_cnt[2]; bs.samples_done += s_cnt[3]; bs.path_steps += path_steps;
     }
 }
 
@@ -615,6 +697,25 @@ void launch_shade(const DScene &sc, const DPass &pass, const DQueue &q, DBlockSt
         case 1: launch(k_shade<FeatLambertTex>); break;
         case 2: launch(k_shade<FeatClassic>); break;
         default: launch(k_shade<FeatAll>); break;
+    }
+}
+// LDS the fused tail needs: the extend image followed by the shade tables; 0 when that does not fit one workgroup's share
+size_t tail_smem(const ExtendConfig &ecfg, const ShadeConfig &scfg) {
+    const size_t at = (ecfg.smem + 15) & ~(size_t)15, total = at + scfg.smem;
+    return total <= 64 * 1024 ? total : 0;
+}
+void launch_tail(const DScene &sc, const DPass &pass, const DQueue &q, DBlockState *blocks, uint32_t n_blocks, uint32_t seg, const ExtendConfig &ecfg, const ShadeConfig &scfg, int *spill, hipStream_t s) {
+    ShadeStage st;
+    st.prims_bytes = scfg.prims_bytes; st.materials_bytes = scfg.materials_bytes; st.lights_bytes = scfg.lights_bytes; st.light_cdf_bytes = scfg.light_cdf_bytes;
+    st.light_tris_bytes = scfg.light_tris_bytes; st.light_tri_cdf_bytes = scfg.light_tri_cdf_bytes; st.stage_prims = scfg.stage_prims;
+    const uint32_t at = (uint32_t)((ecfg.smem + 15) & ~(size_t)15);
+    const size_t smem = tail_smem(ecfg, scfg);
+    auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(n_blocks), dim3(kBlock), smem, s, sc, pass, q, blocks, seg, st, at, ecfg.stack, ecfg.lds_nodes, ecfg.lds_prims, spill); };
+    switch (scfg.variant) {
+        case 0: launch(k_tail<FeatLambert>); break;
+        case 1: launch(k_tail<FeatLambertTex>); break;
+        case 2: launch(k_tail<FeatClassic>); break;
+        default: launch(k_tail<FeatAll>); break;
     }
 }
 void launch_resolve(const DPass &pass, uint32_t n_pixels, float *rgb, hipStream_t s) {
