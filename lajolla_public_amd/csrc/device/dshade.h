@@ -196,7 +196,11 @@ LJ_HD f3 aux_value(const DScene &sc, int integrator, f3 org, f3 dir, float t, fl
 }
 
 // ------------------------------------------------------------------ lights (lights/*.inl, shapes/*.inl sampling)
-struct LightSample { f3 position, normal; };
+// `dpos`: the sampled point in double.  For a sphere light the direction and distance to it must come from this one: a
+// float point sits up to 1e-6 off the sphere, and from a grazing angle a shadow ray then meets the light's own surface
+// some sqrt(2 r 1e-6) before the point — outside the (1 - eps) margin — which shadowed 12 % of the samples of a small,
+// distant sphere light (disney_bsdf_test/simple_sphere.xml).  Triangle lights: the float point, widened.
+struct LightSample { f3 position, normal; double dpos[3]; };
 
 LJ_HD float sphere_one_minus_cos_max(float r, float dist_sq) {
     // 1 - sqrt(1 - r^2/d^2) without cancellation: s / (1 + sqrt(1 - s))
@@ -215,32 +219,42 @@ LJ_HD LightSample sample_point_on_light(const DScene &sc, const DLight &L, f3 re
             float b1 = 1.0f - a, b2 = a * u1;
             ls.position = ld3(T.v0) + ld3(T.e1) * b1 + ld3(T.e2) * b2;
             ls.normal = ld3(T.n);
-        } else {  // sphere.inl:156-204
-            f3 center = ld3(L.center); float r = L.radius;
-            f3 dc_vec = center - ref;
-            float dist_sq = dot(dc_vec, dc_vec);
+            ls.dpos[0] = ls.position.x; ls.dpos[1] = ls.position.y; ls.dpos[2] = ls.position.z;
+        } else {  // sphere.inl:156-204, in the reference's double arithmetic (see LightSample)
+            const double cx = L.center[0], cy = L.center[1], cz = L.center[2], r = L.radius;
+            const double vx = cx - (double)ref.x, vy = cy - (double)ref.y, vz = cz - (double)ref.z;
+            const double dist_sq = vx * vx + vy * vy + vz * vz;
+            double nx, ny, nz;
             if (dist_sq < r * r) {
-                float z = 1.0f - 2.0f * u0;
-                float r_ = sqrtf(fmaxf(0.0f, 1.0f - z * z));
-                float phi = kTwoPi * u1;
-                f3 offset = mk3(r_ * cosf(phi), r_ * sinf(phi), z);
-                ls.position = center + offset * r; ls.normal = offset;
+                const double z = 1.0 - 2.0 * (double)u0;
+                const double r_ = sqrt(fmax(0.0, 1.0 - z * z));
+                const double phi = 2.0 * 3.14159265358979323846 * (double)u1;
+                nx = r_ * cos(phi); ny = r_ * sin(phi); nz = z;
             } else {
-                Frame3 frame = make_frame(normalize(dc_vec));
-                float omc_max = sphere_one_minus_cos_max(r, dist_sq);
-                float omc = u0 * omc_max;                       // 1 - cos_elevation
-                float cos_elevation = 1.0f - omc;
-                float sin_sq = omc * (2.0f - omc);               // 1 - cos^2, stable
-                float azimuth = u1 * kTwoPi;
-                // The reference (pbrt-v3 form, sphere.inl:186-193) gets cos_alpha from dc^2 + r^2 - ds^2, which cancels
-                // catastrophically in float for a small, distant sphere.  This is the same quantity in the
-                // cancellation-free form:  cos_alpha = sin^2(theta)/sin(theta_max) + cos(theta) sqrt(1 - sin^2(theta)/sin^2(theta_max)).
-                float sin_max_sq = r * r / dist_sq, sin_max = sqrtf(sin_max_sq);
-                float cos_alpha = sin_sq / sin_max + cos_elevation * sqrtf(fmaxf(0.0f, 1.0f - sin_sq / sin_max_sq));
-                float sin_alpha = sqrtf(fmaxf(0.0f, 1.0f - cos_alpha * cos_alpha));
-                f3 n = -to_world(frame, mk3(sin_alpha * cosf(azimuth), sin_alpha * sinf(azimuth), cos_alpha));
-                ls.position = n * r + center; ls.normal = n;
+                const double dc = sqrt(dist_sq);
+                const double dx = vx / dc, dy = vy / dc, dz = vz / dc;   // dir_to_center
+                // coordinate_system (frame.h:11-22)
+                double ax, ay, az, bx, by, bz;
+                if (dz < -1.0 + 1e-6) { ax = 0; ay = -1; az = 0; bx = -1; by = 0; bz = 0; }
+                else {
+                    const double a = 1.0 / (1.0 + dz), b = -dx * dy * a;
+                    ax = 1.0 - dx * dx * a; ay = b; az = -dx;
+                    bx = b; by = 1.0 - dy * dy * a; bz = -dy;
+                }
+                const double sin_max_sq = r * r / dist_sq;
+                const double cos_max = sqrt(fmax(0.0, 1.0 - sin_max_sq));
+                const double cos_el = (1.0 - (double)u0) + (double)u0 * cos_max;
+                const double sin_el = sqrt(fmax(0.0, 1.0 - cos_el * cos_el));
+                const double azimuth = (double)u1 * 2.0 * 3.14159265358979323846;
+                const double ds = dc * cos_el - sqrt(fmax(0.0, r * r - dc * dc * sin_el * sin_el));
+                const double cos_alpha = (dc * dc + r * r - ds * ds) / (2.0 * dc * r);
+                const double sin_alpha = sqrt(fmax(0.0, 1.0 - cos_alpha * cos_alpha));
+                const double lx = sin_alpha * cos(azimuth), ly = sin_alpha * sin(azimuth), lz = cos_alpha;
+                nx = -(ax * lx + bx * ly + dx * lz); ny = -(ay * lx + by * ly + dy * lz); nz = -(az * lx + bz * ly + dz * lz);
             }
+            ls.dpos[0] = cx + r * nx; ls.dpos[1] = cy + r * ny; ls.dpos[2] = cz + r * nz;
+            ls.position = mk3((float)ls.dpos[0], (float)ls.dpos[1], (float)ls.dpos[2]);
+            ls.normal = mk3((float)nx, (float)ny, (float)nz);
         }
     } else {  // envmap.inl:7-20 with table_dist.cpp:116-139
         const float *cm = sc.env_tables + L.env_cdf_marg;
@@ -254,6 +268,7 @@ LJ_HD LightSample sample_point_on_light(const DScene &sc, const DLight &L, f3 re
         float az = ((xo + dx) / L.env_w) * kTwoPi, el = ((yo + dy) / L.env_h) * kPi;
         f3 local = mk3(sinf(az) * sinf(el), cosf(el), -cosf(az) * sinf(el));
         ls.position = mk3(0, 0, 0); ls.normal = -xform_vector9(L.to_world, local);
+        ls.dpos[0] = ls.dpos[1] = ls.dpos[2] = 0.0;
     }
     return ls;
 }
@@ -312,9 +327,13 @@ LJ_HD float fresnel_dielectric(float n_dot_i, float eta) {  // microfacet.h:34-5
     float rs = (ni - eta * nt) / (ni + eta * nt), rp = (eta * ni - nt) / (eta * ni + nt);
     return (rs * rs + rp * rp) * 0.5f;
 }
-LJ_HD float GTR2(float n_dot_h, float roughness) {  // microfacet.h:58-63
+// GTR2 (microfacet.h:58-63) from the half vector in the shading frame.  The reference's 1 + (a2 - 1) cos^2 is
+// a2 cos^2 + sin^2; written with sin^2 = hx^2 + hy^2 it keeps its precision in float when the half vector is within
+// 1e-4 of the normal — at the smallest roughness the reference allows (0.01 -> alpha 1e-4) the cos^2 form rounds to
+// exactly 0 there and the BSDF to inf / inf.
+LJ_HD float GTR2(f3 h_local, float roughness) {
     float alpha = roughness * roughness, a2 = alpha * alpha;
-    float t = 1.0f + (a2 - 1.0f) * n_dot_h * n_dot_h;
+    float t = a2 * h_local.z * h_local.z + (h_local.x * h_local.x + h_local.y * h_local.y);
     return a2 / (kPi * t * t);
 }
 LJ_HD float smith_masking_gtr2(f3 v_local, float roughness) {  // microfacet.h:75-81
@@ -460,7 +479,7 @@ LJ_HD void bsdf_eval_pdf(const DScene &sc, const DMaterial &m, f3 dir_in, f3 dir
         float roughness = clampf(tex1<Ft>(sc, m, 2, vx), 0.01f, 1.0f);
         float h_dot_in = dot(h, dir_in);
         float F = fresnel_dielectric(h_dot_in, eta);
-        float D = GTR2(dot(frame.n, h), roughness);
+        float D = GTR2(to_local(frame, h), roughness);
         float G_in = smith_masking_gtr2(to_local(frame, dir_in), roughness);
         float G = G_in * smith_masking_gtr2(to_local(frame, dir_out), roughness);
         float n_dot_in = dot(frame.n, dir_in);
@@ -590,7 +609,7 @@ LJ_HD void bsdf_eval_pdf(const DScene &sc, const DMaterial &m, f3 dir_in, f3 dir
         f3 Kd = tex3<Ft>(sc, m, 0, vx), Ks = tex3<Ft>(sc, m, 1, vx);
         float roughness = clampf(tex1<Ft>(sc, m, 2, vx), 0.01f, 1.0f);
         float F_o = fresnel_dielectric(dot(h, dir_out), m.eta);
-        float D = GTR2(n_dot_h, roughness);
+        float D = GTR2(to_local(frame, h), roughness);
         float G_in = smith_masking_gtr2(to_local(frame, dir_in), roughness);
         float G = G_in * smith_masking_gtr2(to_local(frame, dir_out), roughness);
         f3 spec = Ks * ((G * F_o * D) / (4.0f * n_dot_in * n_dot_out));
@@ -798,11 +817,19 @@ LJ_HD bool shade_path(const DScene &sc, const DPass &pass, PathState &ps, ShadeC
     {
         float G; f3 dir_light; float tfar;
         if (!Ft::envmap || Lt.kind == 0) {
-            f3 dl = pl.position - vx.position;
-            float d2 = dot(dl, dl), d = sqrtf(d2);
-            dir_light = normalize(dl);
-            tfar = (1.0f - sc.eps) * d;
-            G = fmaxf(-dot(dir_light, pl.normal), 0.0f) / d2;
+            if (Ft::sphere_lights && Lt.is_sphere) {   // direction and distance from the double sample point (see LightSample)
+                const double dx = pl.dpos[0] - (double)vx.position.x, dy = pl.dpos[1] - (double)vx.position.y, dz = pl.dpos[2] - (double)vx.position.z;
+                const double d2d = dx * dx + dy * dy + dz * dz, dd = sqrt(d2d);
+                dir_light = mk3((float)(dx / dd), (float)(dy / dd), (float)(dz / dd));
+                tfar = (float)((1.0 - (double)sc.eps) * dd);
+                G = fmaxf(-dot(dir_light, pl.normal), 0.0f) / (float)d2d;
+            } else {
+                f3 dl = pl.position - vx.position;
+                float d2 = dot(dl, dl), d = sqrtf(d2);
+                dir_light = normalize(dl);
+                tfar = (1.0f - sc.eps) * d;
+                G = fmaxf(-dot(dir_light, pl.normal), 0.0f) / d2;
+            }
         } else { dir_light = -pl.normal; tfar = INFINITY; G = 1.0f; }
         float p1 = Lt.pmf * pdf_point_on_light<Ft>(sc, Lt, pl.position, pl.normal, vx.position);
         if (G > 0.0f && p1 > 0.0f) {

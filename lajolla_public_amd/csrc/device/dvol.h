@@ -107,16 +107,26 @@ LJ_HD f3 vol_nee(const DScene &sc, Tracer &tr, VolRng &rng, f3 p, int current_me
     const int light_id = sample_cdf(sc.light_cdf, sc.n_lights, light_w);
     const DLight &Lt = sc.lights[light_id];
     const LightSample pl = sample_point_on_light(sc, Lt, p, lu0, lu1, shape_w);
-    const f3 dir_light = normalize(pl.position - p);
+    // direction and distances from the double sample point (LightSample, dshade.h): exact on a sphere light
+    auto dist_to = [&](f3 from) {
+        const double dx = pl.dpos[0] - (double)from.x, dy = pl.dpos[1] - (double)from.y, dz = pl.dpos[2] - (double)from.z;
+        return sqrt(dx * dx + dy * dy + dz * dz);
+    };
+    f3 dir_light;
+    {
+        const double dd = dist_to(p);
+        dir_light = mk3((float)((pl.dpos[0] - (double)p.x) / dd), (float)((pl.dpos[1] - (double)p.y) / dd), (float)((pl.dpos[2] - (double)p.z) / dd));
+    }
     const f3 p_prime = pl.position, p_origin = p;
     int shadow_medium = current_medium, shadow_bounces = 0;
     f3 T = mk3(1, 1, 1), p_trans_nee = mk3(1, 1, 1), p_trans_dir = mk3(1, 1, 1);
     // (every pass moves p at least eps along the ray, so the walk ends; the cap only bounds a degenerate scene)
     for (int segment = 0;; segment++) {
         if (segment >= 4096) return mk3(0, 0, 0);
-        const float dist_to_light = length(p_prime - p);
+        const double dist_d = dist_to(p);
+        const float dist_to_light = (float)dist_d;
         float t, hu, hv; int gprim;
-        const bool hit = tr.closest(p, dir_light, sc.eps, (1.0f - sc.eps) * dist_to_light, t, hu, hv, gprim);
+        const bool hit = tr.closest(p, dir_light, sc.eps, (float)((1.0 - (double)sc.eps) * dist_d), t, hu, hv, gprim);
         DVertex sv;
         float next_t = dist_to_light;
         if (hit) { sv = build_vertex(sc, p, dir_light, t, hu, hv, gprim, 0.0f); next_t = length(sv.position - p); }
