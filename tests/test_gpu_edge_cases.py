@@ -1,0 +1,82 @@
+"""Edge cases of the render entry points on the GPU: degenerate crops, odd sample counts, tiny and huge path pools, rank
+counts that do not divide the tiles (or exceed them), depth limits — every result against the oracle or against an
+equivalent render, bit for bit where the quantity is deterministic."""
+import numpy as np
+import pytest
+
+import lajolla_public_amd as lj
+from lajolla_public_amd import _abi
+from helpers import Oracle, scene_path
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cbox():
+    hs = lj.parse_scene(scene_path("cbox"))
+    return hs, lj.Scene(lj.Context(0), hs), Oracle(hs)
+
+
+def test_single_pixel_and_border_crops(cbox):
+    hs, sc, o = cbox
+    full = lj.render(sc, spp=3)
+    for crop in [(0, 0, 1, 1), (511, 511, 512, 512), (0, 511, 512, 512), (255, 0, 256, 512), (17, 33, 18, 34)]:
+        x0, y0, x1, y1 = crop
+        c = lj.render(sc, spp=3, crop=crop)
+        same = bool(np.array_equal(c[y0:y1, x0:x1], full[y0:y1, x0:x1]))
+        outside = c.copy(); outside[y0:y1, x0:x1] = 0
+        assert same and not outside.any(), crop
+        ps = lj.render_samples(sc, crop, spp=3)
+        assert ps.shape == (y1 - y0, x1 - x0, 3, 3)
+        rc, _, ref, _ = o.render(spp=3, crop=crop, per_sample=True)
+        rel = np.abs(ps - ref).max(axis=-1) / np.maximum(np.abs(ref).max(axis=-1), 1e-3)
+        assert np.median(rel) < 2e-5   # (a single pixel has three samples: not much of a median)
+
+
+def test_pool_sizes_and_sample_counts_do_not_change_a_bit(cbox):
+    hs, sc, o = cbox
+    crop = (100, 100, 228, 164)
+    for spp in (1, 2, 7, 33):
+        a = lj.render(sc, spp=spp, crop=crop)
+        for pool in (4096, 5000, 1 << 16, 1 << 20, 1 << 25):
+            same = bool(np.array_equal(a, lj.render(sc, spp=spp, crop=crop, pool_paths=pool)))
+            assert same, (spp, pool)
+
+
+def test_rank_counts_that_do_not_divide_the_tiles(cbox):
+    hs, sc, o = cbox
+    a = lj.render(sc, spp=2)
+    for world in (3, 7):
+        acc = np.zeros_like(a)
+        for r in range(world):
+            acc += lj.render(sc, spp=2, rank=r, world_size=world)
+        same = bool(np.array_equal(acc, a))
+        assert same, world
+    # more ranks than tiles: the ranks beyond the last tile render nothing
+    assert not lj.render(sc, spp=2, rank=1500, world_size=2000).any()
+    assert sc.stats().samples == 0
+    with pytest.raises(lj.LajollaError) as e:
+        lj.render(sc, spp=2, rank=2, world_size=2)
+    assert e.value.code == _abi.LJ_ERR_INVALID_ARG
+
+
+def test_depth_limits(cbox):
+    hs, sc, o = cbox
+    crop = (200, 20, 312, 84)   # the luminaire and the ceiling around it
+    for md in (0, 1, 2, 5):
+        ps = lj.render_samples(sc, crop, spp=2, max_depth=md)
+        rc, _, ref, _ = o.render(spp=2, crop=crop, per_sample=True, max_depth=md)
+        rel = np.abs(ps - ref).max(axis=-1) / np.maximum(np.abs(ref).max(axis=-1), 1e-3)
+        assert np.isfinite(ps).all() and np.median(rel) < 2e-6 and (rel > 1e-3).mean() < 0.03, md
+    # path_tracing.h:58-66: with max_depth 0 or 1 the bounce loop never runs — only directly visible emission is left
+    d0, d1 = lj.render_samples(sc, crop, spp=2, max_depth=0), lj.render_samples(sc, crop, spp=2, max_depth=1)
+    same = bool(np.array_equal(d0, d1))
+    assert same and d0.max() > 1.0 and (d0 == 0).mean() > 0.5
+
+
+def test_bad_arguments_are_refused(cbox):
+    hs, sc, o = cbox
+    for kw in (dict(crop=(-1, 0, 8, 8)), dict(crop=(0, 0, 513, 8)), dict(rank=-1, world_size=2)):
+        with pytest.raises(lj.LajollaError) as e:
+            lj.render(sc, **{"spp": 1, **kw})
+        assert e.value.code == _abi.LJ_ERR_INVALID_ARG
