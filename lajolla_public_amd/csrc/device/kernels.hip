@@ -1,15 +1,20 @@
 // gfx950 kernels of the wavefront integrator.  Written for wave64 / 256-thread workgroups / 160 KB LDS per CU.
 //
 //   k_extend    persistent   : closest hit of the extension ray + any hit of the pending shadow ray over the
-//                              flattened BVH.  Persistent waves walk a slice of the queue; a lane whose rays are done
-//                              pulls the next path instead of idling until the slowest lane of the wave finishes
-//                              (while-while traversal with dynamic refill).  Top of the tree, leaf primitives of
-//                              small scenes and the per-lane traversal stacks live in LDS.  (intersection.cpp:7-85)
+//                              flattened BVH4.  Persistent waves draw 256-slot chunks of live paths from the list the
+//                              preceding shade launch left; a lane whose rays are done pulls the next path instead of
+//                              idling until the slowest lane of the wave finishes (while-while traversal with dynamic
+//                              refill).  Top of the tree, leaf primitives of small scenes and the per-lane traversal
+//                              stacks live in LDS.  (intersection.cpp:7-85)
 //   k_shade     block/segment: hit accounting, NEE, BSDF sampling, Russian roulette (path_tracing.h:58-322).  Each
 //                              workgroup owns one segment of the queue: survivors are compacted to the front of the
 //                              segment in order (wave ballots + a 4-entry LDS scan), then the workgroup's next camera
-//                              samples (path_tracing.h:10-14) are appended behind them.  No grid-wide atomic exists.
+//                              samples (path_tracing.h:10-14) are appended behind them and its live chunks listed.
+//                              Instantiated per scene feature set (ShadeFeat).
+//   k_tail      block/segment: the end of a render, fused: trace + shade + compact in a loop inside one launch
 //   k_resolve   wave/pixel   : fixed-order sum of the per-sample radiance -> radiance / spp (render.cpp:94)
+//   k_aux                    : the five auxiliary buffers (render.cpp:12-69)
+//   k_volpath   lane/sample  : the volumetric path tracer (vol_path_tracing.h:503-869), one whole path per lane
 //   k_trace_rays             : batched intersect()/occluded() for the parity tests
 #include <hip/hip_runtime.h>
 #include "dshade.h"
