@@ -32,10 +32,8 @@ def check_samples(got, ref):
     assert (rel > 1e-3).mean() < 0.03
     assert abs(g.mean() / r.mean() - 1) < 2e-3
     d = (np.minimum(g, 8.0) - np.minimum(r, 8.0)).sum(axis=-1)
-    # zero-mean differences, up to 3e-4 of the total: a point sampled in float on the silhouette of a sphere light can
-    # fall just behind the horizon and be shadowed by the light itself, where the double-precision point is just visible
-    # (its contribution is small — the light-side cosine vanishes there — but it is always lost, never gained)
-    assert abs(d.sum()) <= 4.0 * np.sqrt((d * d).sum()) + 3e-4 * np.abs(r).sum() + 1e-6
+    # zero-mean differences (beyond the 1e-5 relative bias that rounding the scene constants to float may leave)
+    assert abs(d.sum()) <= 4.0 * np.sqrt((d * d).sum()) + 1e-5 * np.abs(r).sum() + 1e-6
 
 
 def test_absorbing_medium_matches_the_closed_form():
