@@ -1,0 +1,47 @@
+"""`python -m lajolla_public_amd [-o output_file_name] [--spp N] filename.xml ...` — the reference's driver loop
+(main.cpp:12-51) on the HIP path: parse, render, write to `-o` or the scene's own output file name (PFM / EXR).
+`-t num_threads` is accepted and ignored (the render does not run on host threads)."""
+import sys
+import time
+
+from . import Context, Scene, parse_scene, render, write_image
+
+
+def main(argv):
+    if not argv:
+        print("[Usage] python -m lajolla_public_amd [-t num_threads] [-o output_file_name] [--spp N] filename.xml")
+        return 0
+    output, spp, filenames = "", 0, []
+    i = 0
+    while i < len(argv):
+        if argv[i] == "-t":
+            i += 1
+        elif argv[i] == "-o":
+            i += 1
+            output = argv[i]
+        elif argv[i] == "--spp":
+            i += 1
+            spp = int(argv[i])
+        else:
+            filenames.append(argv[i])
+        i += 1
+    ctx = Context(0)
+    for filename in filenames:
+        t0 = time.perf_counter()
+        print(f"Parsing and constructing scene {filename}.")
+        hs = parse_scene(filename)
+        sc = Scene(ctx, hs)
+        print(f"Done. Took {time.perf_counter() - t0:.6g} seconds.")
+        print("Rendering...")
+        t0 = time.perf_counter()
+        img = render(sc, spp=spp)
+        if output == "":
+            output = hs.desc.output_filename.decode()
+        print(f"Done. Took {time.perf_counter() - t0:.6g} seconds.")
+        write_image(output, img)
+        print(f"Image written to {output}")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1:]))

@@ -109,3 +109,9 @@ def test_unsupported_variants_fail_loudly():
     with pytest.raises(RuntimeError) as e:
         Twin(hs)
     assert "integrator" in str(e.value)
+
+
+def test_driver_prints_the_usage_line_without_arguments(capsys):
+    from lajolla_public_amd.__main__ import main
+    assert main([]) == 0
+    assert capsys.readouterr().out.startswith("[Usage]")

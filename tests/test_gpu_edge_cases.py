@@ -80,3 +80,35 @@ def test_bad_arguments_are_refused(cbox):
         with pytest.raises(lj.LajollaError) as e:
             lj.render(sc, **{"spp": 1, **kw})
         assert e.value.code == _abi.LJ_ERR_INVALID_ARG
+
+
+def test_driver_loop_writes_what_render_returns(cbox, tmp_path, capsys):
+    """main.cpp:12-51 — parse, render, imwrite to `-o`, the same messages."""
+    from lajolla_public_amd.__main__ import main
+    hs, sc, o = cbox
+    out = tmp_path / "cbox.pfm"
+    assert main(["-t", "4", "-o", str(out), "--spp", "2", scene_path("cbox")]) == 0
+    said = capsys.readouterr().out
+    assert "Parsing and constructing scene" in said and "Rendering..." in said and f"Image written to {out}" in said
+    raw = out.read_bytes()
+    head = b"PF\n512 512\n-1\n"
+    same = raw[:len(head)] == head and raw[len(head):] == lj.render(sc, spp=2).tobytes()
+    assert same
+
+
+def test_fused_tail_and_lanes_do_not_change_a_bit(cbox, monkeypatch):
+    """The end of a render runs fused (k_tail: wavefront steps inside a workgroup, then one path per lane in registers) and a
+    render is cut into two lanes; neither may change a sample."""
+    hs, sc, o = cbox
+    a = lj.render(sc, spp=6)
+    assert sc.stats().samples == 512 * 512 * 6
+    monkeypatch.setenv("LJ_TUNE_TAIL", "0")
+    b = lj.render(sc, spp=6)
+    monkeypatch.setenv("LJ_TUNE_LANES", "1")
+    c = lj.render(sc, spp=6)
+    monkeypatch.delenv("LJ_TUNE_TAIL")
+    d = lj.render(sc, spp=6)
+    monkeypatch.setenv("LJ_TUNE_TAIL_FRAC", "16")   # fuse from the moment every camera sample has been started
+    e = lj.render(sc, spp=6)
+    same = [bool(np.array_equal(a, x)) for x in (b, c, d, e)]
+    assert all(same), same
