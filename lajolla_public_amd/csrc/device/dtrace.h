@@ -39,16 +39,14 @@ LJ_HD bool tri_test_raw(const RayF &r, float tfar, const float *p0, const float 
     float W = LJ_TRI_DOT(LJ_TRI_CROSS(e2y, s2z, e2z, s2y), LJ_TRI_CROSS(e2z, s2x, e2x, s2z), LJ_TRI_CROSS(e2x, s2y, e2y, s2x), r.dx, r.dy, r.dz);
     float mn = fminf(fminf(U, V), W), mx = fmaxf(fmaxf(U, V), W);
     if (!(mn >= 0.0f || mx <= 0.0f)) return false;
+    // (most tests end above; what is left runs straight through — one exit, no nest of branches around the division)
     float S = (U + V) + W;
-    if (S == 0.0f) return false;
     float nx = LJ_TRI_CROSS(e1y, e0z, e1z, e0y), ny = LJ_TRI_CROSS(e1z, e0x, e1x, e0z), nz = LJ_TRI_CROSS(e1x, e0y, e1y, e0x);
     float den = LJ_TRI_DOT(nx, ny, nz, r.dx, r.dy, r.dz);
-    if (den == 0.0f) return false;
     float T = LJ_TRI_DOT(nx, ny, nz, ax, ay, az);
     float t = T / den;
-    if (!(t > r.tnear && t <= tfar)) return false;
     t_out = t; U_out = U; V_out = V; S_out = S;
-    return true;
+    return (S != 0.0f) & (den != 0.0f) & (t > r.tnear) & (t <= tfar);
 }
 LJ_HD bool tri_test(const RayF &r, float tfar, const float *p0, const float *p1, const float *p2, float &t_out, float &u_out, float &v_out) {
     float U, V, S;

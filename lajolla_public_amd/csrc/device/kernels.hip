@@ -206,11 +206,14 @@ __device__ __forceinline__ void trav_leaf_step(const TreeView &tv, LaneTrav &L, 
         const int gprim = __float_as_int(p0.w), kind = __float_as_int(p1.w);
         if (!SPHERES || kind == 0) {
             const float v0[3] = {p0.x, p0.y, p0.z}, v1[3] = {p1.x, p1.y, p1.z}, v2[3] = {p2.x, p2.y, p2.z};
-            float t, U, V, S;
-            if (tri_test_raw(L.ray, L.best.t, v0, v1, v2, t, U, V, S)) {
-                if (ANY_HIT) { L.best.gprim = gprim; stop = true; }
-                else if (t < L.best.t || (t == L.best.t && (L.best.gprim < 0 || gprim < L.best.gprim))) { L.best.t = t; L.best.u = U; L.best.v = V; L.best_S = S; L.best.gprim = gprim; }
-            }
+            float t = 0.0f, U = 0.0f, V = 0.0f, S = 1.0f;
+            const bool hit = tri_test_raw(L.ray, L.best.t, v0, v1, v2, t, U, V, S);
+            // selects, not branches: an any-hit ray only needs `gprim` (and stops), a closest-hit ray takes the nearer of
+            // (t, gprim); what the other fields of an any-hit ray hold no longer matters
+            const bool take = hit & (ANY_HIT | (t < L.best.t) | ((t == L.best.t) & ((L.best.gprim < 0) | (gprim < L.best.gprim))));
+            L.best.t = take ? t : L.best.t; L.best.u = take ? U : L.best.u; L.best.v = take ? V : L.best.v;
+            L.best_S = take ? S : L.best_S; L.best.gprim = take ? gprim : L.best.gprim;
+            stop = hit & ANY_HIT;
         } else {
             double td;
             if (sphere_test(L.ray, tv.spheres[__float_as_int(p2.w)], td)) {
