@@ -94,7 +94,9 @@ constexpr uint32_t kChunk = 256;   // queue slots a wave draws at a time (segmen
 constexpr int kDone = 0x7fffffff;  // "no more work for this ray" marker in `cur`
 
 struct LaneTrav {
-    RayF ray; float ix, iy, iz;
+    RayF ray;
+    // slab constants: t = fma(plane, i, -oi) with i = 1 / d, oi = o * i
+    float ix, iy, iz, oix, oiy, oiz;
     HitRec best;     // for a triangle hit u, v hold the unnormalised barycentrics U, V until trav_finish divides by best_S
     float best_S;
     int cur, sp;
@@ -106,6 +108,11 @@ __device__ __forceinline__ void trav_begin(LaneTrav &L, float tnear, float tfar)
     // v_rcp_f32 (1 ulp) is enough here: the slabs only steer the traversal, and the boxes carry a 1e-5 pad plus a 4-ulp
     // widening of the exit distance; hits are decided by the primitive tests alone
     L.ix = __builtin_amdgcn_rcpf(L.ray.dx); L.iy = __builtin_amdgcn_rcpf(L.ray.dy); L.iz = __builtin_amdgcn_rcpf(L.ray.dz);
+    // One fma per plane instead of subtract + multiply.  (plane - o) * i is exact where plane ~ o and the fma is not, but
+    // its error there, ulp(o * i), is a hundredth of what the builder's 1e-5 box padding amounts to in t; away from that
+    // both forms carry the same rounding of o.  A direction component of 0 gives i = inf and o * i = inf or nan: the
+    // planes of that axis then all read nan, which fmax / fmin ignore — the axis drops out of the test (conservative).
+    L.oix = L.ray.ox * L.ix; L.oiy = L.ray.oy * L.iy; L.oiz = L.ray.oz * L.iz;
     L.nqx = L.ix < 0.0f ? 3u : 0u; L.nqy = L.iy < 0.0f ? 4u : 1u; L.nqz = L.iz < 0.0f ? 5u : 2u;
     L.best.t = tfar; L.best.u = 0.0f; L.best.v = 0.0f; L.best.gprim = -1; L.best_S = 1.0f;
     L.cur = 0; L.sp = 0;
@@ -158,15 +165,13 @@ __device__ __forceinline__ void trav_node_step(const TreeView &tv, LaneTrav &L) 
         nz = *(const v4f *)(g + (o + L.nqz * 16u)); fz = *(const v4f *)(g + (o + (7u - L.nqz) * 16u));
         ch = *(const v4f *)(g + (o + 96u));
     }
-    const v4f tnx = (nx - L.ray.ox) * L.ix, tfx = (fx - L.ray.ox) * L.ix;
-    const v4f tny = (ny - L.ray.oy) * L.iy, tfy = (fy - L.ray.oy) * L.iy;
-    const v4f tnz = (nz - L.ray.oz) * L.iz, tfz = (fz - L.ray.oz) * L.iz;
     const float inf = __builtin_inff();
+
     float t0[4]; int c[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const float te = fmaxf(fmaxf(tnx[k], tny[k]), fmaxf(tnz[k], L.ray.tnear));
-        const float tx = fminf(fminf(tfx[k], tfy[k]), fminf(tfz[k], L.best.t));
+        const float te = fmaxf(fmaxf(__builtin_fmaf(nx[k], L.ix, -L.oix), __builtin_fmaf(ny[k], L.iy, -L.oiy)), fmaxf(__builtin_fmaf(nz[k], L.iz, -L.oiz), L.ray.tnear));
+        const float tx = fminf(fminf(__builtin_fmaf(fx[k], L.ix, -L.oix), __builtin_fmaf(fy[k], L.iy, -L.oiy)), fminf(__builtin_fmaf(fz[k], L.iz, -L.oiz), L.best.t));
         t0[k] = (te <= tx * 1.0000005f) ? te : inf;
         c[k] = __float_as_int(ch[k]);
     }
