@@ -411,7 +411,10 @@ using FeatClassic = ShadeFeat<0x007u, true, true, true>;         // diffuse, rou
 #ifndef LJ_LAMBERT_OCC
 #define LJ_LAMBERT_OCC 4
 #endif
-template <class Ft> struct ShadeOccupancy { static constexpr int waves = 4; };
+#ifndef LJ_SHADE_OCC
+#define LJ_SHADE_OCC 3   // the feature sets beyond Lambert-only need ~150 VGPRs: at 4 waves they spill (sponza -2 %, matpreview -3 % at 3)
+#endif
+template <class Ft> struct ShadeOccupancy { static constexpr int waves = LJ_SHADE_OCC; };
 template <> struct ShadeOccupancy<FeatLambert> { static constexpr int waves = LJ_LAMBERT_OCC; };
 
 template <class Ft>
