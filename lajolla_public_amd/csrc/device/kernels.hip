@@ -257,7 +257,10 @@ __global__ void __launch_bounds__(kBlock, (RESIDENT && !SPHERES && !STATS) ? LJ_
     uint32_t next = 0, end = 0;             // live slots of the open chunk (wave-uniform)
     bool exhausted = false;
     // per-lane state: phase 0 = shadow ray (any hit), phase 1 = extension ray (closest hit)
-    bool busy = false; int phase = 0; uint32_t path = 0; uint32_t flags = 0; int vis = 0;
+    // `start`: the ray this lane has to set up before it traverses again — 1 = its pending shadow ray, 2 = its extension
+    // ray; written by the refill (a new path) and by the end of a shadow ray, consumed at ONE place, so that the ray set-up
+    // code exists once and the traversal state is rewritten in one region of the loop only
+    bool busy = false; int phase = 0; uint32_t path = 0; uint32_t flags = 0; int vis = 0; int start = 0;
     float edx = 0, edy = 0, edz = 0;
     LaneTrav L; L.cur = kDone; L.sp = 0;
     for (;;) {
@@ -289,14 +292,19 @@ __global__ void __launch_bounds__(kBlock, (RESIDENT && !SPHERES && !STATS) ? LJ_
                 vis = 0; busy = true;
                 if (ro.w > 0.0f) {  // pending NEE shadow ray [eps, tfar] (path_tracing.h:124-128)
                     const Rec4 rs = q.rs[path];
-                    L.ray.dx = rs.x; L.ray.dy = rs.y; L.ray.dz = rs.z;
-                    trav_begin(L, sc.eps, ro.w); phase = 0;
-                } else if (!(flags & PF_NO_EXT)) {  // extension ray [eps, inf); camera rays start at 0 (camera.cpp:46, path_tracing.h:236)
-                    L.ray.dx = edx; L.ray.dy = edy; L.ray.dz = edz;
-                    trav_begin(L, ((flags & 0xffffu) == 2u) ? 0.0f : sc.eps, INFINITY); phase = 1;
-                } else { q.rh[path] = mk4(0.0f, 0.0f, 0.0f, u2f(0u)); busy = false; }
+                    L.ray.dx = rs.x; L.ray.dy = rs.y; L.ray.dz = rs.z; L.ray.tfar = ro.w;
+                    start = 1;
+                } else if (!(flags & PF_NO_EXT)) start = 2;
+                else { q.rh[path] = mk4(0.0f, 0.0f, 0.0f, u2f(0u)); busy = false; }
             }
             next += n_idle < left ? n_idle : left;
+        }
+        if (start != 0) {
+            // shadow ray [eps, tfar]; extension ray [eps, inf), camera rays from 0 (camera.cpp:46, path_tracing.h:236)
+            const bool ext = start == 2;
+            if (ext) { L.ray.dx = edx; L.ray.dy = edy; L.ray.dz = edz; }
+            trav_begin(L, (ext && (flags & 0xffffu) == 2u) ? 0.0f : sc.eps, ext ? INFINITY : L.ray.tfar);
+            phase = ext ? 1 : 0; start = 0;
         }
         if (__ballot(busy) == 0ull) { if (exhausted && next == end) break; else continue; }
         if (STATS) { st_outer++; st_busy += __popcll(__ballot(busy)); }
@@ -325,10 +333,8 @@ __global__ void __launch_bounds__(kBlock, (RESIDENT && !SPHERES && !STATS) ? LJ_
         if (busy && L.cur == kDone) {
             if (phase == 0) {
                 vis = (L.best.gprim < 0) ? HIT_VIS_BIT : 0;
-                if (!(flags & PF_NO_EXT)) {
-                    L.ray.dx = edx; L.ray.dy = edy; L.ray.dz = edz;
-                    trav_begin(L, sc.eps, INFINITY); phase = 1;  // a path with a pending shadow ray is never a camera ray
-                } else { q.rh[path] = mk4(0.0f, 0.0f, 0.0f, u2f((uint32_t)vis)); busy = false; }
+                if (!(flags & PF_NO_EXT)) { start = 2; L.cur = 0; }   // (cur leaves kDone here: this block must not run twice)
+                else { q.rh[path] = mk4(0.0f, 0.0f, 0.0f, u2f((uint32_t)vis)); busy = false; }
             } else {
                 const uint32_t code = (uint32_t)vis | (uint32_t)(L.best.gprim + 1);
                 const bool hit = L.best.gprim >= 0;
