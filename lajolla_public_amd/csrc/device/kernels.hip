@@ -122,7 +122,15 @@ __device__ __forceinline__ void trav_push(const TreeView &tv, LaneTrav &L, int v
     else tv.spill[(uint32_t)(L.sp - tv.cap) * tv.spill_stride] = v;
     L.sp++;
 }
+template <bool RESIDENT = false>
 __device__ __forceinline__ int trav_pop(const TreeView &tv, LaneTrav &L) {
+    if (RESIDENT) {   // every level is in LDS: one read, no branch (and no global load for the scheduler to wait on)
+        const int sp = L.sp > 0 ? L.sp - 1 : 0;
+        const int v = tv.stack[sp * kBlock];
+        const int r = L.sp > 0 ? v : kDone;
+        L.sp = sp;
+        return r;
+    }
     if (L.sp == 0) return kDone;
     L.sp--;
     if (L.sp < tv.cap) return tv.stack[L.sp * kBlock];
@@ -228,7 +236,7 @@ __device__ __forceinline__ void trav_leaf_step(const TreeView &tv, LaneTrav &L, 
             }
         }
     }
-    L.cur = stop ? kDone : trav_pop(tv, L);
+    L.cur = stop ? kDone : trav_pop<RESIDENT>(tv, L);
 }
 
 // STATS: developer instrumentation (LJ_EXTEND_STATS=1): wave-level step counts and the lanes active in them, summed into
