@@ -54,10 +54,11 @@ constexpr uint32_t kMaxBlocks = 8192;
 
 } // namespace
 
+constexpr uint32_t kMaxLanes = 8;   // render lanes (streams) a context can run side by side
 struct lj_context {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t lane_streams[3] = {nullptr, nullptr, nullptr};   // further lanes of a render (run_render)
+    hipStream_t lane_streams[kMaxLanes - 1] = {};   // further lanes of a render (run_render)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int n_cus = 256;
     // workspace, grown on demand and reused across renders
@@ -123,8 +124,8 @@ RenderPlan make_plan(const lj_scene *sc, const LjRenderArgs *a) {
     if (p.spp <= 0) throw LjError(LJ_ERR_INVALID_ARG, "samples per pixel must be positive");
     p.seed = (a && a->seed) ? a->seed : 0x853c49e6748fea9bULL;
     p.max_depth = (a && a->max_depth != INT32_MIN) ? a->max_depth : sc->flat.max_depth;
-    p.pool = (a && a->pool_paths) ? a->pool_paths : (1u << 24);  // 16 M paths in flight = 2 GiB of queue records: long per-wave
-    // slices keep the extend kernel's lanes refilled (a wave's drain phase is amortised over ~2 k paths)
+    p.pool = (a && a->pool_paths) ? a->pool_paths : (1u << 25);  // 32 M paths in flight = 4 GiB of queue records, 8 M per lane:
+    // long per-wave slices keep the extend kernel's lanes refilled (a wave's drain phase is amortised over ~2 k paths)
     p.pool = std::max<uint32_t>(p.pool, 4096);
     if (a && a->rng_mode != LJ_RNG_SAMPLE) throw LjError(LJ_ERR_UNSUPPORTED, "only LJ_RNG_SAMPLE exists on the device (a per-tile sequential stream cannot be parallelised, SURVEY §0.2)");
     int rank = a ? a->rank : 0, world = (a && a->world_size > 0) ? a->world_size : 1;
@@ -182,7 +183,7 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
         const uint64_t pass_samples_max = pix_per_pass * (uint64_t)plan.spp;
         if (ctx->sample_rgb.bytes < pass_samples_max * 12) ctx->sample_rgb.alloc(pass_samples_max * 12);
         if (ctx->pixel_list.bytes < n_pix * 4) ctx->pixel_list.alloc(n_pix * 4);
-        if (!ctx->chunk_counter.p) ctx->chunk_counter.alloc(512);
+        if (!ctx->chunk_counter.p) ctx->chunk_counter.alloc(128 * kMaxLanes);
         HIP_CHECK(hipMemcpyAsync(ctx->pixel_list.p, plan.pixels.data(), n_pix * 4, hipMemcpyHostToDevice, stream));
         HIP_CHECK(hipMemsetAsync(ctx->chunk_counter.p, 0, 8, stream));
         HIP_CHECK(hipEventRecord(ctx->ev_begin, stream));
@@ -216,16 +217,17 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
     uint32_t pool = (uint32_t)std::min<uint64_t>(plan.pool, std::max<uint64_t>(pass_samples_max, 256));
     uint32_t blocks_per_cu = 8;
     if (const char *e = getenv("LJ_TUNE_BLOCKS_PER_CU")) blocks_per_cu = (uint32_t)std::max(1, atoi(e));
-    // Two lanes: the pool, its workgroup segments and the pass's samples are split in two halves that advance
-    // independently on two streams.  The extend kernel is bound by VALU issue and moves few bytes, the shade kernel
-    // streams the queue and leaves the VALUs mostly idle; with two lanes the GPU usually has one of each to run side by
-    // side.  (One lane when kernels are timed individually, for tiny renders, or on request.)
+    // Lanes: the pool, its workgroup segments and the pass's samples are split into four parts that advance
+    // independently on four streams.  The extend kernel is bound by VALU issue and moves few bytes, the shade kernel
+    // streams the queue and leaves the VALUs mostly idle; with four staggered lanes the GPU always has some of each to
+    // run side by side (two lanes: +13 % time on cbox; six or eight: worse again — more streams than hardware queues).
+    // (One lane when kernels are timed individually or for tiny renders, two for small ones, or on request.)
     // developer instrumentation of the extend kernel (utilisation counters printed to stderr); off unless asked for
     unsigned long long *xstats = nullptr;
     DevBuf xstats_buf;
     if (getenv("LJ_EXTEND_STATS")) { xstats_buf.alloc(64); HIP_CHECK(hipMemsetAsync(xstats_buf.p, 0, 64, stream)); xstats = (unsigned long long *)xstats_buf.p; }
-    uint32_t n_lanes = (timing || xstats || pool < (1u << 20)) ? 1u : 2u;
-    if (const char *e = getenv("LJ_TUNE_LANES")) n_lanes = (uint32_t)std::min(4, std::max(1, atoi(e)));
+    uint32_t n_lanes = (timing || xstats || pool < (1u << 20)) ? 1u : (pool < (1u << 22) ? 2u : 4u);
+    if (const char *e = getenv("LJ_TUNE_LANES")) n_lanes = (uint32_t)std::min((int)kMaxLanes, std::max(1, atoi(e)));
     uint32_t n_blocks = std::min<uint32_t>(kMaxBlocks, std::max<uint32_t>(n_lanes, std::min<uint32_t>((uint32_t)ctx->n_cus * blocks_per_cu, pool / 256)));
     n_blocks = (n_blocks / n_lanes) * n_lanes;
     const uint32_t lane_blocks = n_blocks / n_lanes;
@@ -233,9 +235,9 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
     const uint32_t n_slots = n_blocks * seg, lane_slots = lane_blocks * seg;
     ensure_queues(ctx, n_slots);
     // extend: persistent workgroups that draw 256-slot chunks of the queue.  One lane: more workgroups than fit at once, so
-    // the hardware keeps every CU as full as registers and LDS allow; two lanes: few enough that the other lane's shade
-    // workgroups find room beside them.
-    uint32_t ext_per_cu = n_lanes == 1 ? 8 : 4;
+    // the hardware keeps every CU as full as registers and LDS allow; several lanes: few enough that the other lanes'
+    // shade workgroups find registers beside them (8 extend waves per CU and lane).
+    uint32_t ext_per_cu = n_lanes == 1 ? 8 : (n_lanes == 2 ? 4 : 2);
     if (const char *e = getenv("LJ_TUNE_EXTEND_BLOCKS_PER_CU")) ext_per_cu = (uint32_t)std::max(1, atoi(e));
     const uint32_t lane_chunks = lane_slots / 256u;
     const uint32_t ext_grid = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)ctx->n_cus * ext_per_cu, (lane_chunks + 3) / 4));
@@ -247,13 +249,13 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
     int *spill_base = ensure_spill(ctx, sc->ecfg.spill_levels, spill_grid * n_lanes);
     // per lane: work[0] = the extend kernel's draw counter, work[1 + parity] = number of listed chunks; two chunk lists, used
     // alternately, so that a shade launch can append to one while nothing reads it
-    if (!ctx->chunk_counter.p) ctx->chunk_counter.alloc(512);
+    if (!ctx->chunk_counter.p) ctx->chunk_counter.alloc(128 * kMaxLanes);
     if (ctx->chunk_list.bytes < (size_t)lane_chunks * 8 * n_lanes) ctx->chunk_list.alloc((size_t)lane_chunks * 8 * n_lanes);
     const ljd::DQueue q_all = carve_queue(ctx->queue_mem.p, ctx->queue_capacity);
     struct Lane {
         hipStream_t stream; ljd::DQueue q; ljd::DBlockState *dblocks; ljd::DBlockState *hblocks;
         uint32_t *work; uint32_t *lists[2]; uint32_t parity; int *spill; int *spill_tail; bool done; int batch;
-    } lanes[4];
+    } lanes[kMaxLanes];
     for (uint32_t l = 0; l < n_lanes; l++) {
         Lane &L = lanes[l];
         L.stream = l == 0 ? stream : ctx->lane_streams[l - 1];
@@ -287,7 +289,7 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
             }
             HIP_CHECK(hipMemcpyAsync(ctx->blocks.p, ctx->blocks_host, sizeof(ljd::DBlockState) * n_blocks, hipMemcpyHostToDevice, stream));
         }
-        HIP_CHECK(hipMemsetAsync(ctx->chunk_counter.p, 0, 512, stream));
+        HIP_CHECK(hipMemsetAsync(ctx->chunk_counter.p, 0, 128 * kMaxLanes, stream));
         if (n_lanes > 1) {  // the second lane starts once the pass's inputs are in place
             HIP_CHECK(hipEventRecord(ctx->ev_fork, stream));
             for (uint32_t l = 1; l < n_lanes; l++) HIP_CHECK(hipStreamWaitEvent(ctx->lane_streams[l - 1], ctx->ev_fork, 0));
@@ -304,7 +306,7 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
         }
         // Round-robin over the lanes: look at a lane's block states only when its previous batch has drained, and give it
         // its next batch at once, so the other lane's kernels keep the GPU busy during this lane's host round trip.
-        bool pending[4] = {false, false, false, false};
+        bool pending[kMaxLanes] = {};
         for (int guard = 0; guard < (1 << 21); guard++) {
             bool any = false;
             for (uint32_t l = 0; l < n_lanes; l++) {
