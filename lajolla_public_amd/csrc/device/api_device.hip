@@ -359,18 +359,18 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
             }
             if (!any) break;
         }
-        uint64_t samples_done = 0, path_steps = 0;
+        uint64_t samples_done = 0, path_steps = 0, shadow_rays = 0;
         for (uint32_t b = 0; b < n_blocks; b++) {
             const ljd::DBlockState &bs = ctx->blocks_host[b];
-            samples_done += bs.samples_done; path_steps += bs.path_steps;
+            samples_done += bs.samples_done; path_steps += bs.path_steps; shadow_rays += bs.rays_shadow;
             st.bounce_iterations += bs.bounce_iterations; st.rays_closest += bs.rays_closest; st.rays_shadow += bs.rays_shadow;
         }
         if (samples_done != total)
             throw LjError(LJ_ERR_INTERNAL, "wavefront loop ended with " + std::to_string(samples_done) + " of " + std::to_string(total) + " samples finished");
         st.samples += total;
-        // algorithmic queue traffic: extend reads ro, rd, rs (48 B) and writes rh (16 B) per live path-step;
-        // shade reads 7 records (112 B) and writes 7 records (112 B) per live path-step, plus 12 B per finished sample
-        st.extend_bytes += path_steps * 64ull;
+        // algorithmic queue traffic per live path-step: extend reads ro, rd (32 B), rs (16 B) when a shadow ray
+        // is pending, and writes rh (16 B); shade reads 7 records (112 B) and writes 7 (112 B), plus 12 B per finished sample
+        st.extend_bytes += path_steps * 48ull + shadow_rays * 16ull;
         st.shade_bytes += path_steps * 224ull + total * 12ull;
         // (both lanes were synchronised with the host above, so the caller's stream may read what the second lane wrote)
         if (rgb_dev) ljd::launch_resolve(pass, (uint32_t)np, rgb_dev, stream);
