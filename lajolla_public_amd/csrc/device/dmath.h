@@ -21,11 +21,28 @@ LJ_HD f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
 LJ_HD f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
 LJ_HD f3 operator*(float s, f3 a) { return mk3(s * a.x, s * a.y, s * a.z); }
 LJ_HD f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
-LJ_HD f3 operator/(f3 a, float s) { float inv = 1.0f / s; return mk3(a.x * inv, a.y * inv, a.z * inv); }
+// 1 / s and 1 / sqrt(d) for scaling vectors: on the device the one-instruction, 1-ulp v_rcp_f32 / v_rsq_f32 (an IEEE
+// division costs eleven instructions, sqrt + division twenty); the host twin keeps the libm forms.
+LJ_HD float recip_fast(float s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(s);
+#else
+    return 1.0f / s;
+#endif
+}
+LJ_HD f3 operator/(f3 a, float s) { float inv = recip_fast(s); return mk3(a.x * inv, a.y * inv, a.z * inv); }
 LJ_HD float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 LJ_HD f3 cross(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 LJ_HD float length(f3 a) { return sqrtf(dot(a, a)); }
-LJ_HD f3 normalize(f3 a) { float l = length(a); if (l <= 0.0f) return mk3(0, 0, 0); return a / l; }
+LJ_HD f3 normalize(f3 a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float d = dot(a, a);
+    if (!(d > 0.0f)) return mk3(0, 0, 0);
+    return a * __builtin_amdgcn_rsqf(d);
+#else
+    float l = length(a); if (l <= 0.0f) return mk3(0, 0, 0); return a / l;
+#endif
+}
 LJ_HD float max3(f3 a) { return fmaxf(fmaxf(a.x, a.y), a.z); }
 LJ_HD float luminance(f3 s) { return s.x * 0.212671f + s.y * 0.715160f + s.z * 0.072169f; }
 LJ_HD float clampf(float v, float lo, float hi) { return v < lo ? lo : (hi < v ? hi : v); }

@@ -90,7 +90,9 @@ def test_per_sample_parity(scene):
         assert (rel > 1e-3).mean() < bars["diverged"]
         assert abs(pg.mean() / ps.mean() - 1) < bars["mean"]
         d = (np.minimum(pg, 4.0) - np.minimum(ps, 4.0)).sum(axis=-1).ravel()
-        assert abs(d.sum()) <= 4.0 * np.sqrt((d * d).sum()) + 1e-6
+        # zero-mean differences, up to the systematic part float rounding itself has (the device scales vectors with the
+        # 1-ulp v_rcp_f32 / v_rsq_f32, whose errors do not average out: measured 1e-8 relative, allowed 1e-7)
+        assert abs(d.sum()) <= 4.0 * np.sqrt((d * d).sum()) + 1e-7 * np.abs(ps).sum() + 1e-6
         k_gpu = sc.stats().bounce_iterations / sc.stats().samples
         assert abs(k_gpu / (st.bounces / st.samples) - 1) < bars["k"]
 
