@@ -97,18 +97,23 @@ def test_driver_loop_writes_what_render_returns(cbox, tmp_path, capsys):
 
 
 def test_fused_tail_and_lanes_do_not_change_a_bit(cbox, monkeypatch):
-    """The end of a render runs fused (k_tail: wavefront steps inside a workgroup, then one path per lane in registers) and a
-    render is cut into two lanes; neither may change a sample."""
+    """The end of a render runs fused (k_tail) and a render is cut into lanes (four from 4 M paths in flight, two from 1 M);
+    neither may change a sample."""
     hs, sc, o = cbox
-    a = lj.render(sc, spp=6)
-    assert sc.stats().samples == 512 * 512 * 6
+    spp = 17                                       # 4.46 M samples: four lanes by default
+    a = lj.render(sc, spp=spp)
+    assert sc.stats().samples == 512 * 512 * spp
     monkeypatch.setenv("LJ_TUNE_TAIL", "0")
-    b = lj.render(sc, spp=6)
+    b = lj.render(sc, spp=spp)
     monkeypatch.setenv("LJ_TUNE_LANES", "1")
-    c = lj.render(sc, spp=6)
+    c = lj.render(sc, spp=spp)
     monkeypatch.delenv("LJ_TUNE_TAIL")
-    d = lj.render(sc, spp=6)
+    d = lj.render(sc, spp=spp)
+    monkeypatch.setenv("LJ_TUNE_LANES", "3")
+    e = lj.render(sc, spp=spp)
+    monkeypatch.delenv("LJ_TUNE_LANES")
     monkeypatch.setenv("LJ_TUNE_TAIL_FRAC", "16")   # fuse from the moment every camera sample has been started
-    e = lj.render(sc, spp=6)
-    same = [bool(np.array_equal(a, x)) for x in (b, c, d, e)]
+    f = lj.render(sc, spp=spp)
+    g = lj.render(sc, spp=spp, pool_paths=1 << 21)  # two lanes
+    same = [bool(np.array_equal(a, x)) for x in (b, c, d, e, f, g)]
     assert all(same), same
