@@ -410,6 +410,7 @@ __device__ __forceinline__ uint32_t shade_compact_segment(const DScene &sc, cons
 // LDS staging of the shading tables at byte offset `at` of the dynamic segment; rewrites the pointers of `sc`
 __device__ __forceinline__ void stage_shade_tables(DScene &sc, const ShadeStage &stg, uint32_t at) {
     char *p = (char *)lj_smem + at;
+    if (stg.materials_bytes == 0u) return;   // nothing is staged (shade_config: the tables do not fit): the pointers stay global
     if (stg.stage_prims) { lds_copy16(p, sc.prims, stg.prims_bytes); sc.prims = (const DPrimShade *)p; p += stg.prims_bytes; }
     lds_copy16(p, sc.materials, stg.materials_bytes); sc.materials = (const DMaterial *)p; p += stg.materials_bytes;
     lds_copy16(p, sc.lights, stg.lights_bytes); sc.lights = (const DLight *)p; p += stg.lights_bytes;

@@ -117,3 +117,36 @@ def test_fused_tail_and_lanes_do_not_change_a_bit(cbox, monkeypatch):
     g = lj.render(sc, spp=spp, pool_paths=1 << 21)  # two lanes
     same = [bool(np.array_equal(a, x)) for x in (b, c, d, e, f, g)]
     assert all(same), same
+
+
+def test_scene_whose_light_tables_do_not_fit_in_lds(tmp_path):
+    """An emitter of 1800 triangles: the per-workgroup LDS copy of the light tables is skipped (> 24 KiB) and the shade kernel
+    reads them from global memory — same parity bars as everywhere."""
+    n = 30
+    v, f = [], []
+    for j in range(n + 1):
+        for i in range(n + 1):
+            v.append("v %.6f 1.98 %.6f" % (-0.3 + 0.6 * i / n, -0.3 + 0.6 * j / n))
+    for j in range(n):
+        for i in range(n):
+            a, b, c, d = j * (n + 1) + i + 1, j * (n + 1) + i + 2, (j + 1) * (n + 1) + i + 2, (j + 1) * (n + 1) + i + 1
+            f += ["f %d %d %d" % (a, b, c), "f %d %d %d" % (a, c, d)]   # facing -y
+    (tmp_path / "light.obj").write_text("\n".join(v + f) + "\n")
+    (tmp_path / "floor.obj").write_text("v -1 0 -1\nv 1 0 -1\nv 1 0 1\nv -1 0 1\nf 1 3 2\nf 1 4 3\n")
+    xml = tmp_path / "biglight.xml"
+    xml.write_text("""<scene version="0.6.0"><integrator type="path"><integer name="maxDepth" value="3"/></integrator>
+      <sensor type="perspective"><float name="fov" value="60"/><transform name="toWorld"><lookat origin="0, 1, 3.2" target="0, 0.8, 0" up="0, 1, 0"/></transform>
+        <sampler type="independent"><integer name="sampleCount" value="4"/></sampler>
+        <film type="hdrfilm"><integer name="width" value="64"/><integer name="height" value="48"/></film></sensor>
+      <shape type="obj"><string name="filename" value="floor.obj"/><bsdf type="diffuse"><rgb name="reflectance" value="0.6, 0.5, 0.4"/></bsdf></shape>
+      <shape type="obj"><string name="filename" value="light.obj"/><bsdf type="diffuse"><rgb name="reflectance" value="0, 0, 0"/></bsdf>
+        <emitter type="area"><rgb name="radiance" value="6, 5, 4"/></emitter></shape></scene>""")
+    hs = lj.parse_scene(str(xml))
+    sc, o = lj.Scene(lj.Context(0), hs), Oracle(hs)
+    crop = (0, 0, 64, 48)
+    ps = lj.render_samples(sc, crop, spp=4)
+    rc, _, ref, _ = o.render(spp=4, crop=crop, per_sample=True)
+    assert rc == 0 and ref.max() > 1.0
+    rel = np.abs(ps - ref).max(axis=-1) / np.maximum(np.abs(ref).max(axis=-1), 1e-3)
+    assert np.isfinite(ps).all() and np.median(rel) < 2e-6 and (rel > 1e-3).mean() < 0.02
+    assert abs(ps.mean() / ref.mean() - 1) < 2e-4
