@@ -150,3 +150,15 @@ def test_scene_whose_light_tables_do_not_fit_in_lds(tmp_path):
     rel = np.abs(ps - ref).max(axis=-1) / np.maximum(np.abs(ref).max(axis=-1), 1e-3)
     assert np.isfinite(ps).all() and np.median(rel) < 2e-6 and (rel > 1e-3).mean() < 0.02
     assert abs(ps.mean() / ref.mean() - 1) < 2e-4
+
+
+def test_render_cut_into_passes(cbox):
+    """More than 2^27 samples are rendered in several passes over disjoint pixel ranges; the two rank shares of the same
+    render fit one pass each, so their sum pins the multi-pass frame bit for bit."""
+    hs, sc, o = cbox
+    spp = 520                                       # 136 M samples > 2^27
+    whole = lj.render(sc, spp=spp)
+    assert sc.stats().samples == 512 * 512 * spp
+    parts = lj.render(sc, spp=spp, rank=0, world_size=2) + lj.render(sc, spp=spp, rank=1, world_size=2)
+    same = bool(np.array_equal(whole, parts))
+    assert same and bool(np.isfinite(whole).all())
