@@ -469,6 +469,7 @@ int lj_scene_upload(lj_context *ctx, const LjSceneDesc *desc, lj_scene **out) {
             for (const auto &l : F.lights) sphere_lights = sphere_lights || (l.kind == 0 && l.is_sphere);
             sc->scfg.variant = ljd::shade_variant(kinds, textured, F.envmap_light_id >= 0, sphere_lights);
             if (const char *e = getenv("LJ_TUNE_SHADE_VARIANT")) sc->scfg.variant = std::max(sc->scfg.variant, atoi(e));
+            if (sc->scfg.smem == 0) sc->scfg.variant = 3;   // tables too large to stage: one instantiation serves that case
         }
         *out = sc.release();
     });

@@ -408,10 +408,15 @@ __device__ __forceinline__ uint32_t shade_compact_segment(const DScene &sc, cons
 }
 
 // LDS staging of the shading tables at byte offset `at` of the dynamic segment; rewrites the pointers of `sc`
+// STAGE — what the launch stages: 0 nothing (the tables do not fit, shade_config), 1 materials, lights and their cdfs,
+// 2 the per-primitive shading records as well, -1 decided at run time from `stg`.  With a compile-time STAGE the staged
+// pointers are LDS pointers by construction, which the compiler sees: their reads become ds_read instead of flat loads
+// (flat loads wait on the vector-memory counter together with the queue records).
+template <int STAGE>
 __device__ __forceinline__ void stage_shade_tables(DScene &sc, const ShadeStage &stg, uint32_t at) {
     char *p = (char *)lj_smem + at;
-    if (stg.materials_bytes == 0u) return;   // nothing is staged (shade_config: the tables do not fit): the pointers stay global
-    if (stg.stage_prims) { lds_copy16(p, sc.prims, stg.prims_bytes); sc.prims = (const DPrimShade *)p; p += stg.prims_bytes; }
+    if (STAGE == 0 || (STAGE < 0 && stg.materials_bytes == 0u)) return;   // the pointers stay global
+    if (STAGE == 2 || (STAGE < 0 && stg.stage_prims)) { lds_copy16(p, sc.prims, stg.prims_bytes); sc.prims = (const DPrimShade *)p; p += stg.prims_bytes; }
     lds_copy16(p, sc.materials, stg.materials_bytes); sc.materials = (const DMaterial *)p; p += stg.materials_bytes;
     lds_copy16(p, sc.lights, stg.lights_bytes); sc.lights = (const DLight *)p; p += stg.lights_bytes;
     lds_copy16(p, sc.light_cdf, stg.light_cdf_bytes); sc.light_cdf = (const float *)p; p += stg.light_cdf_bytes;
@@ -432,13 +437,13 @@ using FeatClassic = ShadeFeat<0x007u, true, true, true>;         // diffuse, rou
 template <class Ft> struct ShadeOccupancy { static constexpr int waves = LJ_SHADE_OCC; };
 template <> struct ShadeOccupancy<FeatLambert> { static constexpr int waves = LJ_LAMBERT_OCC; };
 
-template <class Ft>
+template <class Ft, int STAGE>
 __global__ void __launch_bounds__(kBlock, ShadeOccupancy<Ft>::waves) k_shade(DScene sc, DPass pass, DQueue q, DBlockState *blocks, uint32_t seg, ShadeStage stg, uint32_t *work, uint32_t *chunk_list, uint32_t parity, uint32_t extend_waves) {
     __shared__ uint32_t s_list_base;
     if (blockIdx.x == 0 && threadIdx.x == 0) work[0] = extend_waves;   // the extend launch that follows draws list entries beyond its own waves from it
     __shared__ uint32_t s_wcnt[2][kBlock / 64];
     __shared__ unsigned long long s_cnt[5];
-    stage_shade_tables(sc, stg, 0u);
+    stage_shade_tables<STAGE>(sc, stg, 0u);
     DBlockState &bs = blocks[blockIdx.x];
     const uint32_t count = bs.count, next_sample = bs.next_sample, end_sample = bs.end_sample;
     if (threadIdx.x < 5) s_cnt[threadIdx.x] = 0ull;
@@ -484,7 +489,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_tail(DScene sc, DPass pass, DQueu
     __shared__ uint32_t s_wcnt[2][kBlock / 64];
     const TreeView tv = stage_tree(sc, stack, lds_nodes, lds_prims, spill, gridDim.x * kBlock, blockIdx.x * kBlock + threadIdx.x);
     DScene ssc = sc;                       // the shading view of the scene: tables in LDS
-    stage_shade_tables(ssc, stg, shade_lds_at);
+    stage_shade_tables<-1>(ssc, stg, shade_lds_at);
     __syncthreads();
     DBlockState &bs = blocks[blockIdx.x];
     uint32_t count = bs.count;
@@ -723,11 +728,18 @@ void launch_shade(const DScene &sc, const DPass &pass, const DQueue &q, DBlockSt
     st.prims_bytes = cfg.prims_bytes; st.materials_bytes = cfg.materials_bytes; st.lights_bytes = cfg.lights_bytes; st.light_cdf_bytes = cfg.light_cdf_bytes;
     st.light_tris_bytes = cfg.light_tris_bytes; st.light_tri_cdf_bytes = cfg.light_tri_cdf_bytes; st.stage_prims = cfg.stage_prims;
     auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(n_blocks), dim3(kBlock), cfg.smem, s, sc, pass, q, blocks, seg, st, work, chunk_list, parity, extend_waves); };
-    switch (cfg.variant) {
-        case 0: launch(k_shade<FeatLambert>); break;
-        case 1: launch(k_shade<FeatLambertTex>); break;
-        case 2: launch(k_shade<FeatClassic>); break;
-        default: launch(k_shade<FeatAll>); break;
+    // (a scene whose tables are not staged at all runs the all-features instantiation: lj_scene_upload sets variant 3)
+    const int stage = cfg.smem == 0 ? 0 : (cfg.stage_prims ? 2 : 1);
+    switch (stage == 0 ? 30 : cfg.variant * 10 + stage) {
+        case 1: launch(k_shade<FeatLambert, 1>); break;
+        case 2: launch(k_shade<FeatLambert, 2>); break;
+        case 11: launch(k_shade<FeatLambertTex, 1>); break;
+        case 12: launch(k_shade<FeatLambertTex, 2>); break;
+        case 21: launch(k_shade<FeatClassic, 1>); break;
+        case 22: launch(k_shade<FeatClassic, 2>); break;
+        case 31: launch(k_shade<FeatAll, 1>); break;
+        case 32: launch(k_shade<FeatAll, 2>); break;
+        default: launch(k_shade<FeatAll, 0>); break;
     }
 }
 // LDS the fused tail needs: the extend image followed by the shade tables; 0 when that does not fit one workgroup's share
