@@ -17,6 +17,7 @@
 //   k_volpath   lane/sample  : the volumetric path tracer (vol_path_tracing.h:503-869), one whole path per lane
 //   k_trace_rays             : batched intersect()/occluded() for the parity tests
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "dshade.h"
 #include "dvol.h"
 #include "dtrace.h"
@@ -660,9 +661,15 @@ ExtendConfig extend_config(int n_nodes, int n_prims, int bvh_depth, int n_sphere
     ExtendConfig c;
     c.spheres = n_spheres > 0 ? 1 : 0;
     const int need = 3 * (bvh_depth < 1 ? 1 : bvh_depth);
-    c.stack = need < 16 ? need : 16;
+    // LDS image: small scenes (which may become fully resident) get 16 stack levels and up to 40 KiB; for the others 12
+    // levels + 24 KiB (the top ~100 nodes) do as well as 16 + 40 (sponza -1 %, disney_bsdf -4 %; 64 KiB: +30 % — it crowds
+    // out the other workgroups of the CU)
+    int cap = n_prims <= 256 ? 16 : 12, kib = n_prims <= 256 ? 40 : 24;
+    if (const char *e = getenv("LJ_TUNE_EXT_STACK")) cap = atoi(e);
+    if (const char *e = getenv("LJ_TUNE_EXT_LDS_KB")) kib = atoi(e);
+    c.stack = need < cap ? need : cap;
     c.spill_levels = need - c.stack;
-    const int budget = 40 * 1024 - 256 - c.stack * kBlock * 4;
+    const int budget = kib * 1024 - 256 - c.stack * kBlock * 4;
     const int small = n_prims <= 256;                                     // primitives only when the whole scene fits (<= 12 KiB)
     c.lds_prims = small ? n_prims : 0;
     int max_nodes = (budget - c.lds_prims * 48) / 112;
