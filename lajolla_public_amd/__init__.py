@@ -17,7 +17,8 @@ from . import _abi
 from ._abi import LjRenderArgs, LjSceneDesc, LjStats, LjSceneInfo, LjRay, LjHit
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblajolla_hip.so")
+# (LJ_VARIANT: a developer build of the same library with other compile flags, see build.py; unset in every shipped path)
+LIB_PATH = os.path.join(_HERE, "liblajolla_hip" + ("_" + os.environ["LJ_VARIANT"] if os.environ.get("LJ_VARIANT") else "") + ".so")
 _lib = None
 
 

@@ -13,8 +13,11 @@ from concurrent.futures import ThreadPoolExecutor
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "lajolla_public_amd", "csrc")
-BUILD = os.path.join(ROOT, "build")
-LIB = os.path.join(ROOT, "lajolla_public_amd", "liblajolla_hip.so")
+# LJ_VARIANT=name (developer A/B runs, tools/ab.sh): a second library beside the default one, built with
+# LJ_EXTRA_HIPCC_FLAGS into its own object directory and picked up by the package when LJ_VARIANT is set at import
+_VARIANT = os.environ.get("LJ_VARIANT", "")
+BUILD = os.path.join(ROOT, "build" + ("_" + _VARIANT if _VARIANT else ""))
+LIB = os.path.join(ROOT, "lajolla_public_amd", "liblajolla_hip" + ("_" + _VARIANT if _VARIANT else "") + ".so")
 ORACLE_LIB = os.path.join(ROOT, "oracle", "_build", "liblj_oracle.so")
 TWIN_LIB = os.path.join(ROOT, "tests", "twin", "_build", "libljtwin.so")
 
@@ -50,6 +53,18 @@ def _run(cmd):
         raise RuntimeError("command failed: " + " ".join(cmd) + "\n" + r.stdout)
     if r.stdout.strip():
         sys.stderr.write(r.stdout)
+    # the command line is part of an object's cache key (a sidecar next to it): a build with other flags — e.g.
+    # LJ_EXTRA_HIPCC_FLAGS from tools/occ_sweep.sh — is rebuilt by the next default build instead of being silently reused
+    if "-o" in cmd:
+        with open(cmd[cmd.index("-o") + 1] + ".cmd", "w") as f:
+            f.write(" ".join(cmd))
+
+
+def _same_cmd(target, cmd):
+    try:
+        return open(target + ".cmd").read() == " ".join(cmd)
+    except OSError:
+        return False
 
 
 def build_product(verbose=True):
@@ -61,17 +76,19 @@ def build_product(verbose=True):
         s = os.path.join(CSRC, src)
         o = os.path.join(BUILD, src.replace("/", "_") + ".o")
         objs.append(o)
-        if _stale(o, [s] + headers):
-            jobs.append(["g++", "-std=c++17", "-O2", "-fPIC", "-Wall", "-Wno-unused-function", "-c", s, "-o", o])
+        cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-Wall", "-Wno-unused-function", "-c", s, "-o", o]
+        if _stale(o, [s] + headers) or not _same_cmd(o, cmd):
+            jobs.append(cmd)
     for src in HIP_SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(BUILD, src.replace("/", "_") + ".o")
         objs.append(o)
-        if _stale(o, [s] + headers):
-            # -fno-slp-vectorize: packed-fp32 pairs (v_pk_add/mul/fma_f32) cost more in register shuffling than they save
-            # in these kernels (measured: -6 % cbox, -14 % veach_mi, -1..4 % elsewhere; 12 fewer VGPRs in the extend kernel)
-            jobs.append([_hipcc(), "-std=c++17", "-O3", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
-                         "-fno-gpu-rdc", "-fno-slp-vectorize"] + os.environ.get("LJ_EXTRA_HIPCC_FLAGS", "").split() + ["-c", s, "-o", o])
+        # -fno-slp-vectorize: packed-fp32 pairs (v_pk_add/mul/fma_f32) cost more in register shuffling than they save
+        # in these kernels (measured: -6 % cbox, -14 % veach_mi, -1..4 % elsewhere; 12 fewer VGPRs in the extend kernel)
+        cmd = [_hipcc(), "-std=c++17", "-O3", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+               "-fno-gpu-rdc", "-fno-slp-vectorize"] + os.environ.get("LJ_EXTRA_HIPCC_FLAGS", "").split() + ["-c", s, "-o", o]
+        if _stale(o, [s] + headers) or not _same_cmd(o, cmd):
+            jobs.append(cmd)
     if jobs:
         if verbose:
             print(f"[build] compiling {len(jobs)} translation unit(s) for {ARCH}", file=sys.stderr)

@@ -129,6 +129,17 @@ FlatScene flatten_scene(const LjSceneDesc &d) {
     for (int i = 0; i < d.n_materials; i++) {
         const LjMaterial &m = d.materials[i];
         ljd::DMaterial dm{}; dm.kind = m.kind; dm.n_tex = m.n_tex; dm.eta = (float)m.eta;
+        if (m.n_tex < 0 || m.n_tex > LJ_MAX_TEX_SLOTS) throw LjError(LJ_ERR_INVALID_ARG, "material " + std::to_string(i) + ": n_tex out of range");
+        // image textures index the TexturePool (texture.h:13-19): slot 0 of every alternative but DisneyClearcoat, and slot 1
+        // of RoughPlastic / RoughDielectric, are Texture<Spectrum> (image3s); every other slot is a Texture<Real> (image1s)
+        for (int t = 0; t < m.n_tex; t++) {
+            if (m.tex[t].kind != LJ_TEX_IMAGE) continue;
+            const bool spectrum = (t == 0 && m.kind != LJ_MAT_DISNEYCLEARCOAT) || (t == 1 && (m.kind == LJ_MAT_ROUGHPLASTIC || m.kind == LJ_MAT_ROUGHDIELECTRIC));
+            const int n = spectrum ? d.n_images3 : d.n_images1;
+            if (m.tex[t].texture_id < 0 || m.tex[t].texture_id >= n)
+                throw LjError(LJ_ERR_INVALID_ARG, "material " + std::to_string(i) + " slot " + std::to_string(t) + ": texture_id " + std::to_string(m.tex[t].texture_id) +
+                              " outside the " + (spectrum ? "3" : "1") + "-channel image pool (" + std::to_string(n) + " images)");
+        }
         for (int t = 0; t < LJ_MAX_TEX_SLOTS; t++) dm.tex[t] = conv_tex(m.tex[t]);
         F.materials.push_back(dm);
     }

@@ -329,7 +329,7 @@ inline bool sphere_test(const float o[3], const float d[3], float tnear, float t
 
 // ------------------------------------------------------------------ scene (scene.h / scene.cpp)
 struct OMesh { const double *P, *N, *UV; const int32_t *I; int64_t nv, nt; bool has_n, has_uv; Real total_area = 0; TableDist1D tri_sampler; std::vector<float> Pf; long long gprim0 = 0; };
-struct BvhNode { float lo[3], hi[3]; int left, right, first, count; };
+struct BvhNode { float lo[3], hi[3]; int left, right, first, count, axis; };
 struct OScene {
     LjSceneDesc d;
     std::vector<LjShape> shapes; std::vector<LjMaterial> materials; std::vector<LjLight> lights;
@@ -1127,24 +1127,32 @@ inline bool box_hit(const BvhNode &n, const float o[3], const float inv[3], floa
     }
     return t0 <= t1 * 1.0000005f;
 }
-Hit scene_intersect(const OScene &s, const float o[3], const float d[3], float tnear, float tfar) {
+// ANY: stop at the first accepted primitive (occluded(): "a hit exists in [tnear, tfar]"; which one is irrelevant).
+// The child on the ray's side of the split plane is visited first; since the closest hit is min (t, primitive id), the
+// visiting order changes the work done, never the result.
+template <bool ANY>
+Hit scene_trace(const OScene &s, const float o[3], const float d[3], float tnear, float tfar) {
     Hit best{tfar, 0, 0, -1, -1, (long long)1 << 62, 0.0};
-    if (!s.use_bvh) { for (long long g = 0; g < (long long)s.prim_shape.size(); g++) prim_closest(s, g, o, d, tnear, tfar, best); }
-    else {
+    if (!s.use_bvh) {
+        for (long long g = 0; g < (long long)s.prim_shape.size(); g++) { prim_closest(s, g, o, d, tnear, tfar, best); if (ANY && best.shape_id >= 0) break; }
+    } else {
         float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
         int stack[128], sp = 0; stack[sp++] = 0;
         while (sp) {
             const BvhNode &n = s.nodes[stack[--sp]];
             if (!box_hit(n, o, inv, tnear, best.t)) continue;
-            if (n.count > 0) { for (int i = 0; i < n.count; i++) prim_closest(s, s.prim_order[n.first + i], o, d, tnear, tfar, best); }
+            if (n.count > 0) {
+                for (int i = 0; i < n.count; i++) prim_closest(s, s.prim_order[n.first + i], o, d, tnear, tfar, best);
+                if (ANY && best.shape_id >= 0) break;
+            } else if (d[n.axis] >= 0.0f) { stack[sp++] = n.right; stack[sp++] = n.left; }
             else { stack[sp++] = n.left; stack[sp++] = n.right; }
         }
     }
     return best;
 }
+Hit scene_intersect(const OScene &s, const float o[3], const float d[3], float tnear, float tfar) { return scene_trace<false>(s, o, d, tnear, tfar); }
 bool scene_occluded(const OScene &s, const float o[3], const float d[3], float tnear, float tfar) {
-    Hit h = scene_intersect(s, o, d, tnear, tfar);  // any-hit == "a closest hit exists" for opaque geometry
-    return h.shape_id >= 0;
+    return scene_trace<true>(s, o, d, tnear, tfar).shape_id >= 0;
 }
 
 // Triangle geometry normal the way Embree reports it: (p1-p0)x(p2-p0) on the float vertices.
@@ -1335,7 +1343,7 @@ void build_bvh(OScene &s) {
         int mid = t.first + t.count / 2;
         std::nth_element(s.prim_order.begin() + t.first, s.prim_order.begin() + mid, s.prim_order.begin() + t.first + t.count,
                          [&](int a, int b) { return ctr[3 * a + axis] < ctr[3 * b + axis]; });
-        nd.count = 0; nd.first = 0; nd.left = (int)s.nodes.size(); nd.right = nd.left + 1;
+        nd.count = 0; nd.first = 0; nd.axis = axis; nd.left = (int)s.nodes.size(); nd.right = nd.left + 1;
         s.nodes.push_back(BvhNode{}); s.nodes.push_back(BvhNode{});
         s.nodes[t.node] = nd;
         stack.push_back({nd.left, t.first, mid - t.first}); stack.push_back({nd.right, mid, t.first + t.count - mid});

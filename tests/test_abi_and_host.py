@@ -111,6 +111,35 @@ def test_unsupported_variants_fail_loudly():
     assert "integrator" in str(e.value)
 
 
+def test_out_of_range_texture_ids_are_refused():
+    """An image texture whose id is outside the pool it indexes must be LJ_ERR_INVALID_ARG at upload, not an
+    out-of-bounds device read in eval_texture (lj_scene_upload takes caller-built descriptions)."""
+    for slot, tid in ((0, 0), (0, -1), (0, 7)):   # cbox has no images at all
+        hs = lj.parse_scene(scene_path("cbox"))
+        hs.desc.materials[1].tex[slot].kind = _abi.LJ_TEX_IMAGE
+        hs.desc.materials[1].tex[slot].texture_id = tid
+        with pytest.raises(RuntimeError) as e:
+            Twin(hs)
+        assert "texture_id" in str(e.value)
+    # sponza has ten 3-channel images and no 1-channel one: ids 0..9 pass for a Spectrum slot, 10 does not, and a Real
+    # slot (RoughPlastic roughness) cannot take any
+    hs = lj.parse_scene(scene_path("sponza"))
+    assert hs.desc.n_images3 == 10 and hs.desc.n_images1 == 0
+    hs.desc.materials[0].tex[0].kind = _abi.LJ_TEX_IMAGE
+    hs.desc.materials[0].tex[0].texture_id = 10
+    with pytest.raises(RuntimeError) as e:
+        Twin(hs)
+    assert "texture_id 10" in str(e.value)
+    hs = lj.parse_scene(scene_path("sponza"))
+    hs.desc.materials[0].kind = _abi.MATERIAL_KINDS.index("roughplastic")
+    hs.desc.materials[0].n_tex = 3
+    hs.desc.materials[0].tex[2].kind = _abi.LJ_TEX_IMAGE
+    hs.desc.materials[0].tex[2].texture_id = 0
+    with pytest.raises(RuntimeError) as e:
+        Twin(hs)
+    assert "1-channel" in str(e.value)
+
+
 def test_driver_prints_the_usage_line_without_arguments(capsys):
     from lajolla_public_amd.__main__ import main
     assert main([]) == 0
