@@ -227,6 +227,71 @@ typedef struct LjHit { float t, u, v; int32_t shape_id, prim_id; } LjHit;  /* sh
 int lj_intersect(lj_scene *scene, int64_t n, const LjRay *rays_host, LjHit *hits_host);
 int lj_occluded(lj_scene *scene, int64_t n, const LjRay *rays_host, uint8_t *occluded_host);
 
+/* ---------------------------------------------------------------- per-object queries on the device, batched
+ * The reference's free functions on Material / Light / Shape / Camera / Filter / pcg32, evaluated by the SAME float device
+ * code the shade kernels run (device/dshade.h), one query per lane: what lets a test hold the HIP code value for value
+ * against vectors produced by the reference's own functions (tests/golden) and re-run the reference's unit tests
+ * (src/tests/materials.cpp, filter.cpp, frame.cpp, mipmap.cpp) on the GPU.  Host pointers in, host pointers out; blocking.
+ *
+ * `variant`: which compiled feature set of the device code answers — -1: the one lj_scene_upload chose for
+ * this scene; 0..lj_shade_variant_count()-1: that one, LJ_ERR_INVALID_ARG if it does not cover what the scene holds. */
+int lj_shade_variant_count(void);
+int lj_scene_shade_variant(const lj_scene *scene);
+
+/* The PathVertex fields a BSDF reads (intersection.h:15-35). */
+typedef struct LjVertex {
+    float position[3], geometry_normal[3];
+    float frame_x[3], frame_y[3], frame_n[3];   /* shading_frame (frame.h:24-41) */
+    float uv_screen_size, mean_curvature;
+    double uv[2];                                /* double: tiled texture coordinates */
+    int32_t material_id, light_id;               /* light_id: get_area_light_id(shape), -1 if not an emitter */
+    int32_t shape_id, primitive_id;
+} LjVertex;
+
+/* eval(material, dir_in, dir_out, vertex, pool) (material.h:126), pdf_sample_bsdf (material.h:161) and
+ * sample_bsdf(material, dir_in, vertex, pool, rnd_uv, rnd_w) (material.h:147), TransportDirection::TO_LIGHT. */
+typedef struct LjBsdfQuery { LjVertex vertex; float dir_in[3], dir_out[3], rnd_uv[2], rnd_w; int32_t _pad; } LjBsdfQuery;
+typedef struct LjBsdfResult { float eval[3], pdf; float sample_dir[3], sample_eta, sample_roughness; int32_t sample_valid; } LjBsdfResult;
+int lj_bsdf_queries(lj_scene *scene, int variant, int64_t n, const LjBsdfQuery *queries_host, LjBsdfResult *results_host);
+
+/* sample_point_on_light(light, ref, rnd_uv, rnd_w, scene), pdf_point_on_light of that point and
+ * emission(light, view_dir, footprint, point, scene) (light.h:46-67); light_pmf(scene, id) (scene.cpp:77) beside them. */
+typedef struct LjLightQuery { int32_t light_id; float ref[3], rnd_uv[2], rnd_w, view_dir[3]; } LjLightQuery;
+typedef struct LjLightResult { float position[3], normal[3], pdf, emission[3], pmf; int32_t _pad; double position_d[3]; } LjLightResult;
+int lj_light_queries(lj_scene *scene, int variant, int64_t n, const LjLightQuery *queries_host, LjLightResult *results_host);
+/* sample_light(scene, u) (scene.cpp:73) */
+int lj_sample_light_queries(lj_scene *scene, int64_t n, const float *u_host, int32_t *light_id_host);
+
+/* compute_shading_info + the PathVertex assembly of intersect() (intersection.cpp:38-62, shape.h:92) for a hit record
+ * (shape_id, primitive_id, t, u, v) of the ray (org, dir) whose differential has radius 0 and the given spread
+ * (ray.h:27-42); `emission`: emission(vertex, -dir, scene) (path_tracing.h:58-61) when the shape is an emitter, else 0. */
+typedef struct LjHitQuery { float org[3], dir[3], t, u, v, ray_spread; int32_t shape_id, primitive_id; } LjHitQuery;
+typedef struct LjHitResult { LjVertex vertex; float emission[3]; int32_t _pad; } LjHitResult;
+int lj_vertex_queries(lj_scene *scene, int variant, int64_t n, const LjHitQuery *queries_host, LjHitResult *results_host);
+
+/* sample_primary(camera, screen_pos) (camera.cpp:23-47) for pixel (x, y) and the sub-pixel jitter (jx, jy). */
+typedef struct LjPrimaryQuery { int32_t x, y; float jx, jy; } LjPrimaryQuery;
+typedef struct LjPrimaryResult { float org[3], dir[3]; } LjPrimaryResult;
+int lj_primary_ray_queries(lj_scene *scene, int64_t n, const LjPrimaryQuery *queries_host, LjPrimaryResult *results_host);
+
+/* sample(filter, rnd) (filter.h:47, filters/{box,tent,gaussian}.inl); no scene needed. */
+typedef struct LjFilterQuery { int32_t kind; float param, rnd[2]; } LjFilterQuery;
+int lj_filter_queries(lj_context *ctx, int64_t n, const LjFilterQuery *queries_host, float *offsets_host /* 2 per query */);
+
+/* init_pcg32(stream, seed) then `count` draws (pcg.h:22-68): u32_host[i*count + k] = next_pcg32, real_host = the device's
+ * [0,1) float from the same word (NULL: not wanted).  seed 0: 0x853c49e6748fea9b. */
+int lj_pcg32_queries(lj_context *ctx, int64_t n, const uint64_t *stream_ids_host, uint64_t seed, int32_t count, uint32_t *u32_host, float *real_host);
+
+/* eval(texture, uv, footprint, pool) (texture.h:123-154, mipmap.h:52-89) of a caller-described texture against the scene's
+ * TexturePool; spectrum != 0: Texture<Spectrum> (3 values), else Texture<Real> (value in out[0..2] replicated). */
+typedef struct LjTextureQuery { LjTexture texture; double uv[2]; float footprint; int32_t spectrum; } LjTextureQuery;
+int lj_texture_queries(lj_scene *scene, int64_t n, const LjTextureQuery *queries_host, float *rgb_host /* 3 per query */);
+
+/* to_local(frame, v) / to_world(frame, v) / Frame(n) (frame.h:11-56) */
+typedef struct LjFrameQuery { float n[3], v[3]; } LjFrameQuery;
+typedef struct LjFrameResult { float x[3], y[3], to_local[3], to_world[3]; } LjFrameResult;
+int lj_frame_queries(lj_context *ctx, int64_t n, const LjFrameQuery *queries_host, LjFrameResult *results_host);
+
 /* Counters of the last lj_render* call. */
 typedef struct LjStats {
     uint64_t samples;          /* camera samples traced */

@@ -214,3 +214,99 @@ def occluded(scene, org, dir, tnear=0.0, tfar=np.inf):
     occ = np.zeros(rays.shape[0], np.uint8)
     _check(load_library().lj_occluded(scene._h, rays.shape[0], rays.ctypes.data_as(C.c_void_p), occ.ctypes.data_as(C.c_void_p)))
     return occ.astype(bool)
+
+
+# ------------------------------------------------------------------ per-object queries on the device (lajolla_hip.h)
+# numpy structured arrays with the C structs' layouts in, the same out.  One query per GPU lane, answered by the device
+# functions the shade kernels are built from; there is no host arithmetic behind any of these.
+BSDF_QUERY, BSDF_RESULT = np.dtype(_abi.LjBsdfQuery), np.dtype(_abi.LjBsdfResult)
+LIGHT_QUERY, LIGHT_RESULT = np.dtype(_abi.LjLightQuery), np.dtype(_abi.LjLightResult)
+HIT_QUERY, HIT_RESULT = np.dtype(_abi.LjHitQuery), np.dtype(_abi.LjHitResult)
+PRIMARY_QUERY, PRIMARY_RESULT = np.dtype(_abi.LjPrimaryQuery), np.dtype(_abi.LjPrimaryResult)
+FILTER_QUERY = np.dtype(_abi.LjFilterQuery)
+TEXTURE_QUERY = np.dtype(_abi.LjTextureQuery)
+FRAME_QUERY, FRAME_RESULT = np.dtype(_abi.LjFrameQuery), np.dtype(_abi.LjFrameResult)
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _q(a, dtype):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    return a.reshape(-1)
+
+
+def shade_variant_count():
+    return load_library().lj_shade_variant_count()
+
+
+def scene_shade_variant(scene):
+    return load_library().lj_scene_shade_variant(scene._h)
+
+
+def bsdf_queries(scene, queries, variant=-1):
+    """eval / pdf_sample_bsdf / sample_bsdf (material.h:126,147,161) of the device BSDF code, per query."""
+    q = _q(queries, BSDF_QUERY)
+    r = np.zeros(q.shape[0], BSDF_RESULT)
+    _check(load_library().lj_bsdf_queries(scene._h, int(variant), q.shape[0], _vp(q), _vp(r)))
+    return r
+
+
+def light_queries(scene, queries, variant=-1):
+    """sample_point_on_light / pdf_point_on_light / emission (light.h:46-67) + light_pmf, per query."""
+    q = _q(queries, LIGHT_QUERY)
+    r = np.zeros(q.shape[0], LIGHT_RESULT)
+    _check(load_library().lj_light_queries(scene._h, int(variant), q.shape[0], _vp(q), _vp(r)))
+    return r
+
+
+def sample_light_queries(scene, u):
+    u = np.ascontiguousarray(u, np.float32).reshape(-1)
+    ids = np.zeros(u.shape[0], np.int32)
+    _check(load_library().lj_sample_light_queries(scene._h, u.shape[0], _vp(u), _vp(ids)))
+    return ids
+
+
+def vertex_queries(scene, queries, variant=-1):
+    """compute_shading_info + PathVertex assembly (intersection.cpp:38-62) for given hit records."""
+    q = _q(queries, HIT_QUERY)
+    r = np.zeros(q.shape[0], HIT_RESULT)
+    _check(load_library().lj_vertex_queries(scene._h, int(variant), q.shape[0], _vp(q), _vp(r)))
+    return r
+
+
+def primary_ray_queries(scene, queries):
+    q = _q(queries, PRIMARY_QUERY)
+    r = np.zeros(q.shape[0], PRIMARY_RESULT)
+    _check(load_library().lj_primary_ray_queries(scene._h, q.shape[0], _vp(q), _vp(r)))
+    return r
+
+
+def filter_queries(ctx, queries):
+    q = _q(queries, FILTER_QUERY)
+    r = np.zeros((q.shape[0], 2), np.float32)
+    _check(load_library().lj_filter_queries(ctx._h, q.shape[0], _vp(q), _vp(r)))
+    return r
+
+
+def pcg32_queries(ctx, stream_ids, count, seed=0, reals=True):
+    s = np.ascontiguousarray(stream_ids, np.uint64).reshape(-1)
+    u = np.zeros((s.shape[0], count), np.uint32)
+    f = np.zeros((s.shape[0], count), np.float32) if reals else None
+    _check(load_library().lj_pcg32_queries(ctx._h, s.shape[0], _vp(s), int(seed), int(count), _vp(u), _vp(f) if reals else None))
+    return u, f
+
+
+def texture_queries(scene, queries):
+    q = _q(queries, TEXTURE_QUERY)
+    r = np.zeros((q.shape[0], 3), np.float32)
+    _check(load_library().lj_texture_queries(scene._h, q.shape[0], _vp(q), _vp(r)))
+    return r
+
+
+def frame_queries(ctx, queries):
+    q = _q(queries, FRAME_QUERY)
+    r = np.zeros(q.shape[0], FRAME_RESULT)
+    _check(load_library().lj_frame_queries(ctx._h, q.shape[0], _vp(q), _vp(r)))
+    return r

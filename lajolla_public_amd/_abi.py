@@ -131,6 +131,63 @@ class LjSceneInfo(C.Structure):
                 ("bounds_radius", C.c_double), ("bounds_center", C.c_double * 3), ("shadow_epsilon", C.c_double)]
 
 
+class LjVertex(C.Structure):
+    _fields_ = [("position", C.c_float * 3), ("geometry_normal", C.c_float * 3), ("frame_x", C.c_float * 3), ("frame_y", C.c_float * 3),
+                ("frame_n", C.c_float * 3), ("uv_screen_size", C.c_float), ("mean_curvature", C.c_float), ("uv", C.c_double * 2),
+                ("material_id", C.c_int32), ("light_id", C.c_int32), ("shape_id", C.c_int32), ("primitive_id", C.c_int32)]
+
+
+class LjBsdfQuery(C.Structure):
+    _fields_ = [("vertex", LjVertex), ("dir_in", C.c_float * 3), ("dir_out", C.c_float * 3), ("rnd_uv", C.c_float * 2), ("rnd_w", C.c_float), ("_pad", C.c_int32)]
+
+
+class LjBsdfResult(C.Structure):
+    _fields_ = [("eval", C.c_float * 3), ("pdf", C.c_float), ("sample_dir", C.c_float * 3), ("sample_eta", C.c_float), ("sample_roughness", C.c_float),
+                ("sample_valid", C.c_int32)]
+
+
+class LjLightQuery(C.Structure):
+    _fields_ = [("light_id", C.c_int32), ("ref", C.c_float * 3), ("rnd_uv", C.c_float * 2), ("rnd_w", C.c_float), ("view_dir", C.c_float * 3)]
+
+
+class LjLightResult(C.Structure):
+    _fields_ = [("position", C.c_float * 3), ("normal", C.c_float * 3), ("pdf", C.c_float), ("emission", C.c_float * 3), ("pmf", C.c_float), ("_pad", C.c_int32),
+                ("position_d", C.c_double * 3)]
+
+
+class LjHitQuery(C.Structure):
+    _fields_ = [("org", C.c_float * 3), ("dir", C.c_float * 3), ("t", C.c_float), ("u", C.c_float), ("v", C.c_float), ("ray_spread", C.c_float),
+                ("shape_id", C.c_int32), ("primitive_id", C.c_int32)]
+
+
+class LjHitResult(C.Structure):
+    _fields_ = [("vertex", LjVertex), ("emission", C.c_float * 3), ("_pad", C.c_int32)]
+
+
+class LjPrimaryQuery(C.Structure):
+    _fields_ = [("x", C.c_int32), ("y", C.c_int32), ("jx", C.c_float), ("jy", C.c_float)]
+
+
+class LjPrimaryResult(C.Structure):
+    _fields_ = [("org", C.c_float * 3), ("dir", C.c_float * 3)]
+
+
+class LjFilterQuery(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("param", C.c_float), ("rnd", C.c_float * 2)]
+
+
+class LjTextureQuery(C.Structure):
+    _fields_ = [("texture", LjTexture), ("uv", C.c_double * 2), ("footprint", C.c_float), ("spectrum", C.c_int32)]
+
+
+class LjFrameQuery(C.Structure):
+    _fields_ = [("n", C.c_float * 3), ("v", C.c_float * 3)]
+
+
+class LjFrameResult(C.Structure):
+    _fields_ = [("x", C.c_float * 3), ("y", C.c_float * 3), ("to_local", C.c_float * 3), ("to_world", C.c_float * 3)]
+
+
 # every symbol include/lajolla_hip.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("lj_last_error", C.c_char_p, []),
@@ -150,4 +207,15 @@ SYMBOLS = [
     ("lj_get_stats", C.c_int, [C.c_void_p, C.POINTER(LjStats)]),
     ("lj_scene_info", C.c_int, [C.c_void_p, C.POINTER(LjSceneInfo)]),
     ("lj_image_write", C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.c_void_p]),
+    ("lj_shade_variant_count", C.c_int, []),
+    ("lj_scene_shade_variant", C.c_int, [C.c_void_p]),
+    ("lj_bsdf_queries", C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
+    ("lj_light_queries", C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
+    ("lj_sample_light_queries", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    ("lj_vertex_queries", C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
+    ("lj_primary_ray_queries", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    ("lj_filter_queries", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    ("lj_pcg32_queries", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p]),
+    ("lj_texture_queries", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    ("lj_frame_queries", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
 ]

@@ -2,84 +2,7 @@
 // One context = one HIP device + one stream; one process per GPU (the multi-GPU layer above this is
 // torch.distributed over RCCL, see bench.py).  Every HIP call is checked; failures surface as LJ_ERR_DEVICE with
 // the HIP error string — there is no CPU fallback behind any of these functions.
-#include <hip/hip_runtime.h>
-#include "../host/api_common.h"
-#include "../host/flatten.h"
-#include "dtypes.h"
-#include <algorithm>
-#include <cstdlib>
-#include <cstring>
-#include <memory>
-#include <vector>
-
-namespace ljd {
-struct ExtendConfig { int stack; int spill_levels; int lds_nodes; int lds_prims; int resident; int spheres; size_t smem; uint32_t refill_min, min_descending; };
-struct ShadeConfig { uint32_t prims_bytes, materials_bytes, lights_bytes, light_cdf_bytes, light_tris_bytes, light_tri_cdf_bytes, stage_prims; int variant; size_t smem; };
-ShadeConfig shade_config(size_t n_prims, size_t n_materials, size_t n_lights, size_t n_light_tris, size_t n_light_tri_cdf);
-int shade_variant(uint32_t kinds, bool textured, bool envmap, bool sphere_lights);
-ExtendConfig extend_config(int n_nodes, int n_prims, int bvh_depth, int n_spheres);
-int max_stack_depth();
-void launch_extend(const DScene &sc, const DQueue &q, const DBlockState *blocks, uint32_t grid, uint32_t seg, uint32_t *work, const uint32_t *chunk_list, uint32_t parity, const ExtendConfig &cfg, int *spill, unsigned long long *stats, hipStream_t s);
-void launch_shade(const DScene &sc, const DPass &pass, const DQueue &q, DBlockState *blocks, uint32_t n_blocks, uint32_t seg, const ShadeConfig &cfg, uint32_t *work, uint32_t *chunk_list, uint32_t parity, uint32_t extend_waves, hipStream_t s);
-void launch_resolve(const DPass &pass, uint32_t n_pixels, float *rgb, hipStream_t s);
-size_t tail_smem(const ExtendConfig &ecfg, const ShadeConfig &scfg);
-void launch_tail(const DScene &sc, const DPass &pass, const DQueue &q, DBlockState *blocks, uint32_t n_blocks, uint32_t seg, const ExtendConfig &ecfg, const ShadeConfig &scfg, int *spill, hipStream_t s);
-void launch_aux(const DScene &sc, const uint32_t *pixel_list, uint32_t n_pixels, int integrator, float *rgb, const ExtendConfig &cfg, int *spill, int grid, hipStream_t s);
-void launch_volpath(const DScene &sc, const DPass &pass, uint32_t n_samples, unsigned long long *bounce_counter, const ExtendConfig &cfg, int *spill, int grid, hipStream_t s);
-void launch_trace_rays(const DScene &sc, const void *rays, long long n, void *hits, unsigned char *occ, const ExtendConfig &cfg, int *spill, int grid, hipStream_t s);
-}
-
-namespace {
-
-using lj::LjError;
-
-#define HIP_CHECK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) \
-    throw LjError(LJ_ERR_DEVICE, std::string(#expr) + " failed: " + hipGetErrorString(_e)); } while (0)
-
-struct DevBuf {
-    void *p = nullptr; size_t bytes = 0;
-    void alloc(size_t n) { release(); if (n) { HIP_CHECK(hipMalloc(&p, n)); bytes = n; } }
-    void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
-    ~DevBuf() { release(); }
-    DevBuf() = default; DevBuf(const DevBuf &) = delete; DevBuf &operator=(const DevBuf &) = delete;
-};
-
-template <typename T> void upload(DevBuf &b, const std::vector<T> &v, hipStream_t s) {
-    b.alloc(((std::max<size_t>(v.size(), 1) * sizeof(T)) + 31) & ~(size_t)15);
-    if (!v.empty()) HIP_CHECK(hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
-}
-
-constexpr size_t kQueueSlotBytes = 128;  // eight 16-byte records per path
-constexpr uint32_t kMaxBlocks = 8192;
-
-} // namespace
-
-constexpr uint32_t kMaxLanes = 8;   // render lanes (streams) a context can run side by side
-struct lj_context {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    hipStream_t lane_streams[kMaxLanes - 1] = {};   // further lanes of a render (run_render)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    int n_cus = 256;
-    // workspace, grown on demand and reused across renders
-    DevBuf queue_mem; uint32_t queue_capacity = 0;
-    DevBuf chunk_counter, chunk_list;  // the extend kernel's work counters and the two lists of live queue chunks
-    DevBuf spill;  // overflow levels of the traversal stacks: spill_levels x (grid * 256) ints
-    DevBuf blocks, sample_rgb, pixel_list, frame;
-    ljd::DBlockState *blocks_host = nullptr;  // pinned, kMaxBlocks entries
-    hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_k0 = nullptr, ev_k1 = nullptr;
-};
-
-struct lj_scene {
-    lj_context *ctx = nullptr;
-    lj::FlatScene flat;  // host copy (tables for lj_scene_info; arrays already uploaded)
-    DevBuf nodes, leaf_prims, prims, spheres, materials, lights, light_cdf, light_tris, light_tri_cdf, images3, images1, texels, env_tables;
-    DevBuf media, volume_data, shape_media;
-    ljd::DScene dscene{};
-    ljd::ExtendConfig ecfg{};
-    ljd::ShadeConfig scfg{};
-    LjStats stats{};
-};
+#include "api_internal.h"
 
 namespace {
 
@@ -457,6 +380,10 @@ int lj_scene_upload(lj_context *ctx, const LjSceneDesc *desc, lj_scene **out) {
         d.images3 = (const ljd::DImage *)sc->images3.p; d.images1 = (const ljd::DImage *)sc->images1.p; d.texels = (const float *)sc->texels.p; d.env_tables = (const float *)sc->env_tables.p;
         d.media = (const ljd::DMedium *)sc->media.p; d.volume_data = (const float *)sc->volume_data.p; d.shape_media = (const int32_t *)sc->shape_media.p;
         sc->dscene = d;
+        {   int64_t g = 0;
+            for (int si = 0; si < desc->n_shapes; si++) { sc->shape_first_gprim.push_back(g); g += desc->shapes[si].kind == LJ_SHAPE_SPHERE ? 1 : desc->shapes[si].n_triangles; }
+            sc->shape_first_gprim.push_back(g);
+        }
         if (F.bvh_depth > ljd::max_stack_depth())
             throw LjError(LJ_ERR_INTERNAL, "BVH depth " + std::to_string(F.bvh_depth) + " exceeds the traversal stack");
         sc->ecfg = ljd::extend_config((int)F.nodes.size(), (int)F.leaf_prims.size(), F.bvh_depth, (int)F.n_spheres);
@@ -467,6 +394,7 @@ int lj_scene_upload(lj_context *ctx, const LjSceneDesc *desc, lj_scene **out) {
             uint32_t kinds = 0; bool textured = false, sphere_lights = false;
             for (const auto &m : F.materials) { kinds |= 1u << m.kind; for (int t = 0; t < 12; t++) textured = textured || m.tex[t].kind != 0; }
             for (const auto &l : F.lights) sphere_lights = sphere_lights || (l.kind == 0 && l.is_sphere);
+            sc->feat_kinds = kinds; sc->feat_textured = textured; sc->feat_envmap = F.envmap_light_id >= 0; sc->feat_sphere_lights = sphere_lights;
             sc->scfg.variant = ljd::shade_variant(kinds, textured, F.envmap_light_id >= 0, sphere_lights);
             if (const char *e = getenv("LJ_TUNE_SHADE_VARIANT")) sc->scfg.variant = std::max(sc->scfg.variant, atoi(e));
             if (sc->scfg.smem == 0) sc->scfg.variant = 3;   // tables too large to stage: one instantiation serves that case

@@ -20,6 +20,29 @@ struct ShadeFeat {
     static constexpr bool kind(int k) { return ((KINDS >> k) & 1u) != 0u; }
 };
 using FeatAll = ShadeFeat<0x1ffu, true, true, true>;
+// The feature sets device code is compiled for, smallest first; variant v of a scene = the first one that
+// covers its Material / Texture / Light alternatives.  kinds: bit k = Material alternative k (material.h:102-110).
+using FeatLambert = ShadeFeat<0x001u, false, false, false>;      // constant-colour diffuse surfaces, mesh lights (cbox)
+using FeatLambertTex = ShadeFeat<0x001u, true, false, true>;     // + image / checker textures, sphere lights (sponza)
+using FeatClassic = ShadeFeat<0x007u, true, true, true>;         // diffuse, roughplastic, roughdielectric + everything else
+constexpr int kNumShadeVariants = 4;
+// calls fn(Feat{}) for variant v
+template <class Fn> inline void with_shade_variant(int v, Fn &&fn) {
+    switch (v) {
+        case 0: fn(FeatLambert{}); break;
+        case 1: fn(FeatLambertTex{}); break;
+        case 2: fn(FeatClassic{}); break;
+        default: fn(FeatAll{}); break;
+    }
+}
+inline bool variant_covers(int v, uint32_t kinds, bool textured, bool envmap, bool sphere_lights) {
+    bool ok = false;
+    with_shade_variant(v, [&](auto ft) {
+        using Ft = decltype(ft);
+        ok = (kinds & ~Ft::kinds) == 0u && (Ft::textured || !textured) && (Ft::envmap || !envmap) && (Ft::sphere_lights || !sphere_lights);
+    });
+    return ok;
+}
 
 LJ_HD f3 texel(const DScene &sc, const DImage &img, int level, int x, int y) {
     const DMipLevel lv = img.lv[level];

@@ -425,10 +425,7 @@ __device__ __forceinline__ void stage_shade_tables(DScene &sc, const ShadeStage 
     lds_copy16(p, sc.light_tri_cdf, stg.light_tri_cdf_bytes); sc.light_tri_cdf = (const float *)p;
 }
 
-// Feature sets the shade kernel is compiled for, smallest first.  kinds: bit k = Material alternative k.
-using FeatLambert = ShadeFeat<0x001u, false, false, false>;      // constant-colour diffuse surfaces, mesh lights (cbox)
-using FeatLambertTex = ShadeFeat<0x001u, true, false, true>;     // + image / checker textures, sphere lights (sponza)
-using FeatClassic = ShadeFeat<0x007u, true, true, true>;         // diffuse, roughplastic, roughdielectric + everything else
+// (the feature sets the shade kernel is compiled for — FeatLambert ... FeatAll — are listed in dshade.h)
 #ifndef LJ_LAMBERT_OCC
 #define LJ_LAMBERT_OCC 4
 #endif
@@ -724,11 +721,8 @@ void launch_extend(const DScene &sc, const DQueue &q, const DBlockState *blocks,
 }
 // shade_variant() returns the first (smallest) feature set that covers a scene
 int shade_variant(uint32_t kinds, bool textured, bool envmap, bool sphere_lights) {
-    auto covers = [&](uint32_t k, bool t, bool e, bool s) { return (kinds & ~k) == 0u && (t || !textured) && (e || !envmap) && (s || !sphere_lights); };
-    if (covers(FeatLambert::kinds, FeatLambert::textured, FeatLambert::envmap, FeatLambert::sphere_lights)) return 0;
-    if (covers(FeatLambertTex::kinds, FeatLambertTex::textured, FeatLambertTex::envmap, FeatLambertTex::sphere_lights)) return 1;
-    if (covers(FeatClassic::kinds, FeatClassic::textured, FeatClassic::envmap, FeatClassic::sphere_lights)) return 2;
-    return 3;
+    for (int v = 0; v < kNumShadeVariants; v++) if (variant_covers(v, kinds, textured, envmap, sphere_lights)) return v;
+    return kNumShadeVariants - 1;
 }
 
 void launch_shade(const DScene &sc, const DPass &pass, const DQueue &q, DBlockState *blocks, uint32_t n_blocks, uint32_t seg, const ShadeConfig &cfg, uint32_t *work, uint32_t *chunk_list, uint32_t parity, uint32_t extend_waves, hipStream_t s) {

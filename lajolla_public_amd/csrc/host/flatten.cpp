@@ -314,7 +314,11 @@ FlatScene flatten_scene(const LjSceneDesc &d) {
         for (double c : F.light_cdf_d) F.light_cdf.push_back((float)c);
         for (int li = 0; li < d.n_lights; li++) F.lights[li].pmf = (float)F.light_pmf_d[li];
     } else {
-        throw LjError(LJ_ERR_UNSUPPORTED, "scene has no light: the reference would index an empty light table (path_tracing.h:101-102)");
+        // (the auxiliary integrators never look at a light — the reference's own intersection test builds a Scene without any,
+        // src/tests/intersection.cpp:18-26 — but the path tracers index the table unconditionally)
+        if (d.options.integrator >= LJ_INTEGRATOR_PATH)
+            throw LjError(LJ_ERR_UNSUPPORTED, "scene has no light: the reference would index an empty light table (path_tracing.h:101-102)");
+        F.light_cdf.push_back(0.0f);
     }
     F.light_power_d = power;
     if (F.light_tris.empty()) F.light_tris.push_back(ljd::DLightTri{});

@@ -292,3 +292,140 @@ def set_material(hs, index, mdict):
     import ctypes
     m = material_struct(mdict)
     ctypes.memmove(ctypes.addressof(hs.desc.materials[index]), ctypes.addressof(m), ctypes.sizeof(m))
+
+
+# ------------------------------------------------------------------ per-object queries: one interface, two executors
+class TwinQueries:
+    """lj_*_queries answered by the HOST build of the device headers (tests/twin): the CPU suite's stand-in for the GPU, so
+    that the comparisons of tests/test_device_kats.py are themselves tested before a GPU minute is spent."""
+    name = "twin"
+
+    def __init__(self, hs=None):
+        self.lib = twin_lib()
+        self.tw = Twin(hs) if hs is not None else None
+
+    def variants(self):
+        return [v for v in range(lj.shade_variant_count()) if self.lib.twin_variant_covers(self.tw.h, C.c_int(v))]
+
+    def _v(self, variant):
+        return C.c_int(self.lib.twin_shade_variant(self.tw.h) if variant < 0 else variant)
+
+    def bsdf(self, q, variant=-1):
+        q = np.ascontiguousarray(q, lj.BSDF_QUERY).reshape(-1)
+        r = np.zeros(len(q), lj.BSDF_RESULT)
+        self.lib.twin_bsdf_queries(self.tw.h, self._v(variant), C.c_int64(len(q)), q.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p))
+        return r
+
+    def light(self, q, variant=-1):
+        q = np.ascontiguousarray(q, lj.LIGHT_QUERY).reshape(-1)
+        r = np.zeros(len(q), lj.LIGHT_RESULT)
+        self.lib.twin_light_queries(self.tw.h, self._v(variant), C.c_int64(len(q)), q.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p))
+        return r
+
+    def sample_light(self, u):
+        u = np.ascontiguousarray(u, np.float32).reshape(-1)
+        ids = np.zeros(len(u), np.int32)
+        self.lib.twin_sample_light_queries(self.tw.h, C.c_int64(len(u)), u.ctypes.data_as(C.c_void_p), ids.ctypes.data_as(C.c_void_p))
+        return ids
+
+    def vertex(self, q, variant=-1):
+        q = np.ascontiguousarray(q, lj.HIT_QUERY).reshape(-1)
+        r = np.zeros(len(q), lj.HIT_RESULT)
+        self.lib.twin_vertex_queries(self.tw.h, self._v(variant), C.c_int64(len(q)), q.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p))
+        return r
+
+    def primary(self, q):
+        q = np.ascontiguousarray(q, lj.PRIMARY_QUERY).reshape(-1)
+        r = np.zeros(len(q), lj.PRIMARY_RESULT)
+        self.lib.twin_primary_ray_queries(self.tw.h, C.c_int64(len(q)), q.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p))
+        return r
+
+    def filter(self, q):
+        q = np.ascontiguousarray(q, lj.FILTER_QUERY).reshape(-1)
+        r = np.zeros((len(q), 2), np.float32)
+        self.lib.twin_filter_queries(C.c_int64(len(q)), q.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p))
+        return r
+
+    def pcg32(self, streams, count, seed=0):
+        s = np.ascontiguousarray(streams, np.uint64).reshape(-1)
+        u, f = np.zeros((len(s), count), np.uint32), np.zeros((len(s), count), np.float32)
+        self.lib.twin_pcg32_queries(C.c_int64(len(s)), s.ctypes.data_as(C.c_void_p), C.c_uint64(seed), C.c_int(count), u.ctypes.data_as(C.c_void_p), f.ctypes.data_as(C.c_void_p))
+        return u, f
+
+    def texture(self, q):
+        q = np.ascontiguousarray(q, lj.TEXTURE_QUERY).reshape(-1)
+        r = np.zeros((len(q), 3), np.float32)
+        self.lib.twin_texture_queries(self.tw.h, C.c_int64(len(q)), q.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p))
+        return r
+
+    def frame(self, q):
+        q = np.ascontiguousarray(q, lj.FRAME_QUERY).reshape(-1)
+        r = np.zeros(len(q), lj.FRAME_RESULT)
+        self.lib.twin_frame_queries(C.c_int64(len(q)), q.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p))
+        return r
+
+
+class GpuQueries:
+    """The same interface through the C ABI of liblajolla_hip.so on cuda:0 (queries.hip)."""
+    name = "gpu"
+    _ctx = None
+
+    def __init__(self, hs=None):
+        if GpuQueries._ctx is None:
+            GpuQueries._ctx = lj.Context(0)
+        self.ctx = GpuQueries._ctx
+        self.scene = lj.Scene(self.ctx, hs) if hs is not None else None
+
+    def variants(self):
+        out = []
+        for v in range(lj.shade_variant_count()):
+            try:
+                lj.bsdf_queries(self.scene, np.zeros(0, lj.BSDF_QUERY), v)
+                out.append(v)
+            except lj.LajollaError:
+                pass
+        return out
+
+    def bsdf(self, q, variant=-1):
+        return lj.bsdf_queries(self.scene, q, variant)
+
+    def light(self, q, variant=-1):
+        return lj.light_queries(self.scene, q, variant)
+
+    def sample_light(self, u):
+        return lj.sample_light_queries(self.scene, u)
+
+    def vertex(self, q, variant=-1):
+        return lj.vertex_queries(self.scene, q, variant)
+
+    def primary(self, q):
+        return lj.primary_ray_queries(self.scene, q)
+
+    def filter(self, q):
+        return lj.filter_queries(self.ctx, q)
+
+    def pcg32(self, streams, count, seed=0):
+        return lj.pcg32_queries(self.ctx, streams, count, seed)
+
+    def texture(self, q):
+        return lj.texture_queries(self.scene, q)
+
+    def frame(self, q):
+        return lj.frame_queries(self.ctx, q)
+
+
+def with_materials(hs, material_dicts):
+    """Point a parsed scene's material table at a caller-built array (kept alive on the HostScene).  The shapes keep
+    their material ids, so the table must be at least as long as the original."""
+    import ctypes
+    n0 = hs.desc.n_materials
+    mats = [material_struct(m) for m in material_dicts]
+    arr = (_abi.LjMaterial * max(len(mats), n0))()
+    for i in range(n0):
+        ctypes.memmove(ctypes.addressof(arr[i]), ctypes.addressof(hs.desc.materials[i]), ctypes.sizeof(_abi.LjMaterial))
+    for i, m in enumerate(mats):
+        ctypes.memmove(ctypes.addressof(arr[i]), ctypes.addressof(m), ctypes.sizeof(m))
+    hs._material_override = arr
+    hs.desc.materials = ctypes.cast(arr, ctypes.POINTER(_abi.LjMaterial))
+    hs.desc.n_materials = len(arr)
+    return hs

@@ -32,7 +32,8 @@ def test_library_exports_every_declared_symbol():
 def test_struct_sizes_match_the_header(tmp_path):
     """Compile a tiny C program against the header and compare sizeof() with the ctypes mirror."""
     names = ["LjTexture", "LjMaterial", "LjShape", "LjLight", "LjImage", "LjCamera", "LjVolume", "LjMedium", "LjRenderOptions", "LjSceneDesc", "LjRenderArgs",
-             "LjRay", "LjHit", "LjStats", "LjSceneInfo"]
+             "LjRay", "LjHit", "LjStats", "LjSceneInfo", "LjVertex", "LjBsdfQuery", "LjBsdfResult", "LjLightQuery", "LjLightResult", "LjHitQuery",
+             "LjHitResult", "LjPrimaryQuery", "LjPrimaryResult", "LjFilterQuery", "LjTextureQuery", "LjFrameQuery", "LjFrameResult"]
     src = tmp_path / "sz.c"
     src.write_text('#include <stdio.h>\n#include "lajolla_hip.h"\nint main(){' + "".join(f'printf("%zu\\n", sizeof({n}));' for n in names) + "return 0;}")
     exe = tmp_path / "sz"

@@ -180,6 +180,132 @@ void twin_bsdf(void *tv, int material_id, const double *vx22, const double *dir_
     *sample_eta = bs.eta; *sample_roughness = bs.roughness;
 }
 
+// ---- the per-object queries of include/lajolla_hip.h (lj_bsdf_queries ... lj_frame_queries), answered by the host build of
+// the same device functions queries.hip calls: lets the CPU suite run the very comparisons the GPU suite makes
+// (tests/test_device_kats.py), so that a failure on the GPU box is the device's arithmetic, not the test's logic.
+static DVertex vertex_in(const LjVertex &v) {
+    DVertex vx;
+    vx.position = ld3(v.position); vx.gn = ld3(v.geometry_normal);
+    vx.frame.x = ld3(v.frame_x); vx.frame.y = ld3(v.frame_y); vx.frame.n = ld3(v.frame_n);
+    vx.u = v.uv[0]; vx.v = v.uv[1]; vx.uv_screen_size = v.uv_screen_size;
+    vx.material_id = v.material_id; vx.light_id = v.light_id; vx.gprim = 0; vx.is_sphere = false;
+    return vx;
+}
+static void st3(float *o, f3 v) { o[0] = v.x; o[1] = v.y; o[2] = v.z; }
+
+void twin_bsdf_queries(void *tv, int variant, int64_t n, const LjBsdfQuery *q, LjBsdfResult *r) {
+    const DScene &sc = ((Twin *)tv)->view;
+    with_shade_variant(variant, [&](auto ft) {
+        using Ft = decltype(ft);
+        for (int64_t i = 0; i < n; i++) {
+            const DVertex vx = vertex_in(q[i].vertex);
+            const DMaterial &m = sc.materials[vx.material_id];
+            const f3 din = ld3(q[i].dir_in), dout = ld3(q[i].dir_out);
+            f3 f; float pdf;
+            bsdf_eval_pdf<Ft>(sc, m, din, dout, vx, f, pdf);
+            const BsdfSample bs = bsdf_sample<Ft>(sc, m, din, vx, q[i].rnd_uv[0], q[i].rnd_uv[1], q[i].rnd_w);
+            st3(r[i].eval, f); r[i].pdf = pdf; st3(r[i].sample_dir, bs.dir_out); r[i].sample_eta = bs.eta; r[i].sample_roughness = bs.roughness; r[i].sample_valid = bs.valid ? 1 : 0;
+        }
+    });
+}
+void twin_light_queries(void *tv, int variant, int64_t n, const LjLightQuery *q, LjLightResult *r) {
+    const DScene &sc = ((Twin *)tv)->view;
+    with_shade_variant(variant, [&](auto ft) {
+        using Ft = decltype(ft);
+        for (int64_t i = 0; i < n; i++) {
+            const DLight &L = sc.lights[q[i].light_id];
+            const f3 ref = ld3(q[i].ref);
+            const LightSample ls = sample_point_on_light<Ft>(sc, L, ref, q[i].rnd_uv[0], q[i].rnd_uv[1], q[i].rnd_w);
+            st3(r[i].position, ls.position); st3(r[i].normal, ls.normal);
+            r[i].pdf = pdf_point_on_light<Ft>(sc, L, ls.position, ls.normal, ref);
+            st3(r[i].emission, light_emission<Ft>(sc, L, ld3(q[i].view_dir), ls.normal));
+            r[i].pmf = L.pmf; r[i]._pad = 0;
+            for (int k = 0; k < 3; k++) r[i].position_d[k] = ls.dpos[k];
+        }
+    });
+}
+void twin_sample_light_queries(void *tv, int64_t n, const float *u, int32_t *id) {
+    const DScene &sc = ((Twin *)tv)->view;
+    for (int64_t i = 0; i < n; i++) id[i] = sample_cdf(sc.light_cdf, sc.n_lights, u[i]);
+}
+void twin_vertex_queries(void *tv, int variant, int64_t n, const LjHitQuery *q, LjHitResult *r) {
+    Twin *t = (Twin *)tv;
+    const DScene &sc = t->view;
+    // global primitive id of a (shape, primitive): the shape's first global id + primitive
+    std::vector<int64_t> first;
+    {   int64_t best = -1; (void)best;
+        int n_shapes = 0; for (const auto &p : t->flat.prims) n_shapes = p.shape_id + 1 > n_shapes ? p.shape_id + 1 : n_shapes;
+        first.assign(n_shapes + 1, -1);
+        for (size_t g = 0; g < t->flat.prims.size(); g++) if (first[t->flat.prims[g].shape_id] < 0) first[t->flat.prims[g].shape_id] = (int64_t)g;
+    }
+    with_shade_variant(variant, [&](auto ft) {
+        using Ft = decltype(ft);
+        for (int64_t i = 0; i < n; i++) {
+            const int gprim = (int)(first[q[i].shape_id] + q[i].primitive_id);
+            const f3 org = ld3(q[i].org), dir = ld3(q[i].dir);
+            const DVertex vx = build_vertex(sc, org, dir, q[i].t, q[i].u, q[i].v, gprim, q[i].ray_spread);
+            LjHitResult &o = r[i];
+            st3(o.vertex.position, vx.position); st3(o.vertex.geometry_normal, vx.gn);
+            st3(o.vertex.frame_x, vx.frame.x); st3(o.vertex.frame_y, vx.frame.y); st3(o.vertex.frame_n, vx.frame.n);
+            o.vertex.uv_screen_size = vx.uv_screen_size;
+            DScene s1 = sc; s1.init_spread = q[i].ray_spread;
+            o.vertex.mean_curvature = aux_value(s1, 2, org, dir, q[i].t, q[i].u, q[i].v, gprim).x;
+            o.vertex.uv[0] = vx.u; o.vertex.uv[1] = vx.v;
+            o.vertex.material_id = vx.material_id; o.vertex.light_id = vx.light_id;
+            o.vertex.shape_id = sc.prims[gprim].shape_id; o.vertex.primitive_id = sc.prims[gprim].prim_id;
+            f3 em = mk3(0, 0, 0);
+            if (vx.light_id >= 0) em = light_emission<Ft>(sc, sc.lights[vx.light_id], -dir, vx.gn);
+            st3(o.emission, em); o._pad = 0;
+        }
+    });
+}
+void twin_primary_ray_queries(void *tv, int64_t n, const LjPrimaryQuery *q, LjPrimaryResult *r) {
+    const DScene &sc = ((Twin *)tv)->view;
+    for (int64_t i = 0; i < n; i++) { st3(r[i].org, ld3(sc.cam.org)); st3(r[i].dir, camera_primary_dir(sc.cam, q[i].x, q[i].y, q[i].jx, q[i].jy)); }
+}
+void twin_filter_queries(int64_t n, const LjFilterQuery *q, float *out) {
+    for (int64_t i = 0; i < n; i++) filter_sample(q[i].kind, q[i].param, q[i].rnd[0], q[i].rnd[1], out[2 * i], out[2 * i + 1]);
+}
+void twin_pcg32_queries(int64_t n, const uint64_t *streams, uint64_t seed, int count, uint32_t *u32, float *real) {
+    for (int64_t i = 0; i < n; i++) {
+        const uint64_t inc = pcg32_inc(streams[i]);
+        uint64_t st = pcg32_init(streams[i], seed ? seed : 0x853c49e6748fea9bULL), st2 = st;
+        for (int k = 0; k < count; k++) { u32[i * count + k] = pcg32_next(st, inc); if (real) real[i * count + k] = pcg32_real(st2, inc); }
+    }
+}
+void twin_texture_queries(void *tv, int64_t n, const LjTextureQuery *q, float *rgb) {
+    const DScene &sc = ((Twin *)tv)->view;
+    for (int64_t i = 0; i < n; i++) {
+        const LjTexture &t = q[i].texture;
+        DTexture d{}; d.kind = t.kind; d.texture_id = t.texture_id;
+        for (int k = 0; k < 3; k++) { d.value[k] = (float)t.value[k]; d.color1[k] = (float)t.color1[k]; }
+        d.uscale = (float)t.uscale; d.vscale = (float)t.vscale; d.uoffset = (float)t.uoffset; d.voffset = (float)t.voffset;
+        st3(rgb + 3 * i, eval_texture<FeatAll>(sc, d, q[i].spectrum != 0, q[i].uv[0], q[i].uv[1], q[i].footprint));
+    }
+}
+void twin_frame_queries(int64_t n, const LjFrameQuery *q, LjFrameResult *r) {
+    for (int64_t i = 0; i < n; i++) {
+        const Frame3 f = make_frame(ld3(q[i].n));
+        const f3 v = ld3(q[i].v);
+        st3(r[i].x, f.x); st3(r[i].y, f.y); st3(r[i].to_local, to_local(f, v)); st3(r[i].to_world, to_world(f, v));
+    }
+}
+int twin_shade_variant(void *tv) {
+    Twin *t = (Twin *)tv;
+    uint32_t kinds = 0; bool textured = false, sphere_lights = false;
+    for (const auto &m : t->flat.materials) { kinds |= 1u << m.kind; for (int k = 0; k < 12; k++) textured = textured || m.tex[k].kind != 0; }
+    for (const auto &l : t->flat.lights) sphere_lights = sphere_lights || (l.kind == 0 && l.is_sphere);
+    for (int v = 0; v < kNumShadeVariants; v++) if (variant_covers(v, kinds, textured, t->flat.envmap_light_id >= 0, sphere_lights)) return v;
+    return kNumShadeVariants - 1;
+}
+int twin_variant_covers(void *tv, int v) {
+    Twin *t = (Twin *)tv;
+    uint32_t kinds = 0; bool textured = false, sphere_lights = false;
+    for (const auto &m : t->flat.materials) { kinds |= 1u << m.kind; for (int k = 0; k < 12; k++) textured = textured || m.tex[k].kind != 0; }
+    for (const auto &l : t->flat.lights) sphere_lights = sphere_lights || (l.kind == 0 && l.is_sphere);
+    return variant_covers(v, kinds, textured, t->flat.envmap_light_id >= 0, sphere_lights) ? 1 : 0;
+}
+
 void twin_intersect(void *tv, int64_t n, const LjRay *rays, LjHit *hits) {
     Twin *t = (Twin *)tv;
     const DScene &sc = t->view;
