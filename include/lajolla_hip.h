@@ -211,9 +211,10 @@ typedef struct LjRenderArgs {
 /* Replaces `Image3 render(const Scene&)` (render.h:9; path_render render.cpp:71-101): fills rgb[h][w][3]
  * (row-major, y=0 top, image.h:28-34) with radiance / spp.  Blocking.  `rgb_host` is caller-owned. */
 int lj_render(lj_scene *scene, const LjRenderArgs *args, float *rgb_host);
-/* Same, but into caller-owned DEVICE memory; kernels are enqueued on `hip_stream` (a hipStream_t; NULL = the context's own
- * stream).  Returns once the render has completed on that stream (the wavefront loop reads its device-side counters back
- * every few steps).  This is the hand-off used for the RCCL framebuffer reduce. */
+/* Same, but into caller-owned DEVICE memory, ordered on `hip_stream` (a hipStream_t; NULL: no ordering requested): the render
+ * starts after everything `hip_stream` holds at the call and `hip_stream` waits for the finished frame before anything enqueued
+ * on it later.  (The kernels themselves run on the context's own streams.)  Returns once the render has completed.  This is the
+ * hand-off used for the RCCL framebuffer reduce. */
 int lj_render_device(lj_scene *scene, const LjRenderArgs *args, float *rgb_device, void *hip_stream);
 
 /* Per-sample radiance for the crop window: out[((y-y0)*(x1-x0) + (x-x0))*spp + s][3] — one path_tracing()

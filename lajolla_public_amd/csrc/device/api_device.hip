@@ -337,6 +337,7 @@ int lj_context_create(int device_id, lj_context **out) {
         HIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
         for (auto &ls : ctx->lane_streams) HIP_CHECK(hipStreamCreateWithFlags(&ls, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_caller, hipEventDisableTiming));
         ctx->blocks.alloc(sizeof(ljd::DBlockState) * kMaxBlocks);
         HIP_CHECK(hipHostMalloc((void **)&ctx->blocks_host, sizeof(ljd::DBlockState) * kMaxBlocks, hipHostMallocDefault));
         HIP_CHECK(hipEventCreate(&ctx->ev_begin)); HIP_CHECK(hipEventCreate(&ctx->ev_end));
@@ -352,6 +353,7 @@ void lj_context_destroy(lj_context *ctx) {
     for (auto &ls : ctx->lane_streams) if (ls) { (void)hipStreamSynchronize(ls); (void)hipStreamDestroy(ls); }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->ev_caller) (void)hipEventDestroy(ctx->ev_caller);
     if (ctx->blocks_host) (void)hipHostFree(ctx->blocks_host);
     for (hipEvent_t e : {ctx->ev_begin, ctx->ev_end, ctx->ev_k0, ctx->ev_k1}) if (e) (void)hipEventDestroy(e);
     delete ctx;
@@ -413,12 +415,18 @@ void lj_scene_destroy(lj_scene *scene) {
 int lj_render_device(lj_scene *scene, const LjRenderArgs *args, float *rgb_device, void *hip_stream) {
     return lj::guard([&]() {
         if (!scene || !rgb_device) throw LjError(LJ_ERR_INVALID_ARG, "lj_render_device: null argument");
-        set_device(scene->ctx);
-        hipStream_t s = hip_stream ? (hipStream_t)hip_stream : scene->ctx->stream;
+        lj_context *ctx = scene->ctx;
+        set_device(ctx);
+        // The render always runs on the context's own streams — its lanes were created together and sit on distinct hardware
+        // queues; a caller's stream created later may share a queue with one of them, which serialises two lanes (measured:
+        // 26 -> 32 ms per cbox render) — and is ordered against the caller's stream by events on both sides.
+        hipStream_t caller = (hipStream_t)hip_stream, s = ctx->stream;
+        if (caller) { HIP_CHECK(hipEventRecord(ctx->ev_caller, caller)); HIP_CHECK(hipStreamWaitEvent(s, ctx->ev_caller, 0)); }
         RenderPlan plan = make_plan(scene, args);
         const size_t fb = (size_t)scene->flat.cam.width * scene->flat.cam.height * 3 * sizeof(float);
         HIP_CHECK(hipMemsetAsync(rgb_device, 0, fb, s));
         run_render(scene, plan, rgb_device, nullptr, s, args && (args->flags & 1u));
+        if (caller) { HIP_CHECK(hipEventRecord(ctx->ev_caller, s)); HIP_CHECK(hipStreamWaitEvent(caller, ctx->ev_caller, 0)); }
     });
 }
 

@@ -56,7 +56,7 @@ struct lj_context {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t lane_streams[kMaxLanes - 1] = {};   // further lanes of a render (run_render)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_caller = nullptr;
     int n_cus = 256;
     // workspace, grown on demand and reused across renders
     DevBuf queue_mem; uint32_t queue_capacity = 0;

@@ -222,14 +222,6 @@ class Twin:
         self.lib.twin_aux(self.h, C.c_int(integrator), C.c_int(x0), C.c_int(y0), C.c_int(x1), C.c_int(y1), out.ctypes.data_as(C.c_void_p))
         return out
 
-    def bsdf(self, material_id, vertex22, dir_in, dir_out, rnd_uv, rnd_w):
-        ev, sd = np.zeros(3, np.float32), np.zeros(3, np.float32)
-        pdf, eta, rough = C.c_float(), C.c_float(), C.c_float()
-        valid = C.c_int()
-        self.lib.twin_bsdf(self.h, C.c_int(material_id), dptr(darr(vertex22)), dptr(darr(dir_in)), dptr(darr(dir_out)), dptr(darr(rnd_uv)), C.c_double(rnd_w),
-                           ev.ctypes.data_as(C.c_void_p), C.byref(pdf), C.byref(valid), sd.ctypes.data_as(C.c_void_p), C.byref(eta), C.byref(rough))
-        return ev.astype(float), pdf.value, valid.value, sd.astype(float), eta.value, rough.value
-
     def intersect(self, rays):
         hits = np.zeros(rays.shape[0], lj.HIT_DTYPE)
         self.lib.twin_intersect(self.h, C.c_int64(rays.shape[0]), rays.ctypes.data_as(C.c_void_p), hits.ctypes.data_as(C.c_void_p))

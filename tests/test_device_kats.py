@@ -12,7 +12,7 @@ Each test runs twice: on the GPU (`-m gpu`, the parity test proper) and on the h
 (tests/twin — CPU suite), so the comparison logic and the float tolerances are themselves tested without a GPU.
 
 Float tolerances (the device computes in float, the goldens are double):
-  * BSDF eval / pdf: 2e-5 relative (+1e-7 absolute); GTR-type lobes at low roughness lose digits in `1 - cos^2`-type
+  * BSDF eval / pdf: 2e-5 relative + 1e-7 absolute (2e-4 + 5e-7 in the cases named next); GTR-type lobes at low roughness lose digits in `1 - cos^2`-type
     cancellations: 2e-4 when the material's roughness is below 0.1, when it has a clearcoat lobe (alpha <= 0.1 always) or when
     the lobe is a transmission (DESIGN.md §6);
   * sampled directions: 2e-5 absolute per component (5e-4 under the same low-roughness / transmission condition);
@@ -60,12 +60,15 @@ def _fill_vertex(v, gn, fx, fy, fn, uv, uvs, mid):
 
 
 def _check_bsdf(results, wanted, loose, what):
-    """results: LjBsdfResult array; wanted: list of golden query dicts; loose: per-query bool (low roughness / transmission)."""
+    """results: LjBsdfResult array; wanted: list of golden query dicts; loose: per-query bool (low roughness / transmission).
+    |device - reference| <= tol * |reference| + atol: the absolute part covers the far tails of a lobe, where the value is
+    1e-4 of the lobe's peak and is itself the difference of nearly equal float terms (e.g. h.in + eta h.out of a refraction)."""
     worst = 0.0
     for r, q, lo in zip(results, wanted, loose):
-        tol, dtol = (2e-4, 5e-4) if lo else (2e-5, 2e-5)
-        e = _rel(r["eval"], q["eval"], max(1e-7 / tol, 1e-3 * max(np.abs(q["eval"]).max(), 1e-30))).max()
-        p = _rel(r["pdf"], q["pdf"], 1e-7 / tol).max()
+        tol, atol, dtol = (2e-4, 5e-7, 5e-4) if lo else (2e-5, 1e-7, 2e-5)
+        ev, pdf = np.asarray(r["eval"], float), float(r["pdf"])
+        e = (np.abs(ev - q["eval"]) - atol).max() / max(np.abs(q["eval"]).max(), 1e-30)
+        p = (abs(pdf - q["pdf"]) - atol) / max(abs(q["pdf"]), 1e-30)
         assert e <= tol and p <= tol, (what, "eval/pdf", e, p, r["eval"], q["eval"], r["pdf"], q["pdf"])
         assert int(r["sample_valid"]) == q["sample_valid"], (what, "sample_valid", q)
         if q["sample_valid"]:

@@ -158,28 +158,6 @@ void twin_aux(void *tv, int integrator, int x0, int y0, int x1, int y1, float *o
     }
 }
 
-// device BSDF code on an explicit vertex (same record layout as oracle_bsdf's vertex22), for KAT-level comparisons
-void twin_bsdf(void *tv, int material_id, const double *vx22, const double *dir_in, const double *dir_out, const double *rnd_uv, double rnd_w,
-               float *eval3, float *pdf, int *sample_valid, float *sample_dir3, float *sample_eta, float *sample_roughness) {
-    Twin *t = (Twin *)tv;
-    const DScene &sc = t->view;
-    DVertex vx;
-    vx.position = mk3((float)vx22[0], (float)vx22[1], (float)vx22[2]);
-    vx.gn = mk3((float)vx22[3], (float)vx22[4], (float)vx22[5]);
-    vx.frame.x = mk3((float)vx22[6], (float)vx22[7], (float)vx22[8]); vx.frame.y = mk3((float)vx22[9], (float)vx22[10], (float)vx22[11]);
-    vx.frame.n = mk3((float)vx22[12], (float)vx22[13], (float)vx22[14]);
-    vx.u = vx22[17]; vx.v = vx22[18]; vx.uv_screen_size = (float)vx22[19];
-    vx.material_id = material_id; vx.light_id = -1; vx.gprim = 0; vx.is_sphere = false;
-    const DMaterial &m = sc.materials[material_id];
-    f3 di = mk3((float)dir_in[0], (float)dir_in[1], (float)dir_in[2]), dout = mk3((float)dir_out[0], (float)dir_out[1], (float)dir_out[2]);
-    f3 f; float p;
-    bsdf_eval_pdf(sc, m, di, dout, vx, f, p);
-    BsdfSample bs = bsdf_sample(sc, m, di, vx, (float)rnd_uv[0], (float)rnd_uv[1], (float)rnd_w);
-    eval3[0] = f.x; eval3[1] = f.y; eval3[2] = f.z; *pdf = p;
-    *sample_valid = bs.valid; sample_dir3[0] = bs.dir_out.x; sample_dir3[1] = bs.dir_out.y; sample_dir3[2] = bs.dir_out.z;
-    *sample_eta = bs.eta; *sample_roughness = bs.roughness;
-}
-
 // ---- the per-object queries of include/lajolla_hip.h (lj_bsdf_queries ... lj_frame_queries), answered by the host build of
 // the same device functions queries.hip calls: lets the CPU suite run the very comparisons the GPU suite makes
 // (tests/test_device_kats.py), so that a failure on the GPU box is the device's arithmetic, not the test's logic.
