@@ -225,20 +225,24 @@ def main():
     lj.render_device(scene, frame.data_ptr(), stream=stream.cuda_stream, spp=spp, rank=rank, world_size=world, pool_paths=args.pool, flags=1)
     torch.cuda.synchronize(dev)
     si = scene.stats()
-    kernels = {
-        "k_extend": {"ms": si.extend_ms, "launches": si.extend_launches, "bytes": si.extend_bytes},
-        "k_shade": {"ms": si.shade_ms, "launches": si.shade_launches, "bytes": si.shade_bytes},
-    }
+    if si.mega_launches > 0:   # a tiny scene: one fused persistent launch per pass (mega.hip), no path queue
+        kernels = {"k_mega": {"ms": si.mega_ms, "launches": si.mega_launches, "bytes": si.mega_bytes}}
+    else:
+        kernels = {
+            "k_extend": {"ms": si.extend_ms, "launches": si.extend_launches, "bytes": si.extend_bytes},
+            "k_shade": {"ms": si.shade_ms, "launches": si.shade_launches, "bytes": si.shade_bytes},
+        }
     dom = max(kernels, key=lambda k: kernels[k]["ms"])
     kd = kernels[dom]
     avg_us = kd["ms"] * 1e3 / max(kd["launches"], 1)
     achieved = (kd["bytes"] / max(kd["launches"], 1)) / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
     is_default = os.path.basename(args.scene) == "cbox.xml" and spp == 256 and world == 1
     prof, why_not = profiled_counters(dom) if is_default else (None, "only profiled for the default workload")
-    whole_gbs = (si.extend_bytes + si.shade_bytes) / (ms_per_step * 1e-3) / 1e9
+    whole_gbs = (si.extend_bytes + si.shade_bytes + si.mega_bytes) / (ms_per_step * 1e-3) / 1e9
     # `bound`: the shade kernel streams the queue (HBM); the extend kernel is divergent BVH traversal whose queue traffic is a
     # fraction of its time — it is limited by vector-instruction issue at partial lane occupancy (profiles/<ROUND>_summary.md),
-    # so its HBM fraction is reported for the record, not as the bound it runs against.
+    # so its HBM fraction is reported for the record, not as the bound it runs against.  k_mega keeps the path state in registers:
+    # its only HBM traffic is the finished radiance, and what bounds it is vector-instruction issue (valu_issue_frac).
     roofline = {"bound": "hbm" if dom == "k_shade" else "valu", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": round(achieved / PEAK_HBM_GBS, 5), "frac_of_measured_copy": round(achieved / COPY_HBM_GBS, 5),
                 "traffic": prof["traffic"] if prof else None, "traffic_source": prof["source"] if prof else why_not,

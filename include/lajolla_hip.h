@@ -304,6 +304,8 @@ typedef struct LjStats {
     double extend_ms, shade_ms, generate_ms, resolve_ms; /* per-kernel sums, HIP events */
     uint64_t extend_launches, shade_launches;
     uint64_t extend_bytes, shade_bytes; /* algorithmic bytes of each kernel, summed over launches */
+    /* tiny scenes run as one fused persistent launch per pass (k_mega) instead of extend / shade steps */
+    double mega_ms; uint64_t mega_launches, mega_bytes, path_steps;
 } LjStats;
 int lj_get_stats(const lj_scene *scene, LjStats *out);
 

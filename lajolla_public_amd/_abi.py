@@ -121,7 +121,8 @@ class LjStats(C.Structure):
                 ("render_ms", C.c_double), ("extend_ms", C.c_double), ("shade_ms", C.c_double),
                 ("generate_ms", C.c_double), ("resolve_ms", C.c_double),
                 ("extend_launches", C.c_uint64), ("shade_launches", C.c_uint64),
-                ("extend_bytes", C.c_uint64), ("shade_bytes", C.c_uint64)]
+                ("extend_bytes", C.c_uint64), ("shade_bytes", C.c_uint64),
+                ("mega_ms", C.c_double), ("mega_launches", C.c_uint64), ("mega_bytes", C.c_uint64), ("path_steps", C.c_uint64)]
 
 
 class LjSceneInfo(C.Structure):

@@ -135,6 +135,62 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
         st.render_ms = ms; st.bounce_iterations = nb;
         return;
     }
+    // ---- tiny scenes (flat leaf table, shading tables in LDS): the fused persistent kernel, one launch per pass (mega.hip)
+    const size_t mega_lds = ljd::mega_smem(sc->dscene, sc->scfg);
+    const bool mega_off = getenv("LJ_TUNE_MEGA") && atoi(getenv("LJ_TUNE_MEGA")) == 0;
+    if (mega_lds > 0 && !mega_off) {
+        const uint64_t pass_samples_max = pix_per_pass * (uint64_t)plan.spp;
+        if (ctx->sample_rgb.bytes < pass_samples_max * 12) ctx->sample_rgb.alloc(pass_samples_max * 12);
+        if (ctx->pixel_list.bytes < n_pix * 4) ctx->pixel_list.alloc(n_pix * 4);
+        if (!ctx->mega_state.p) ctx->mega_state.alloc(64);
+        HIP_CHECK(hipMemcpyAsync(ctx->pixel_list.p, plan.pixels.data(), n_pix * 4, hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipEventRecord(ctx->ev_begin, stream));
+        int per_cu = ljd::mega_blocks_per_cu(sc->scfg);
+        if (const char *e = getenv("LJ_TUNE_MEGA_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(e));
+        uint32_t grab = 1024;   // camera samples a wave takes off the counter at a time: a multiple of 64 so that a wave's lanes share pixels
+        if (const char *e = getenv("LJ_TUNE_MEGA_GRAB")) grab = (uint32_t)std::max(64, atoi(e)) & ~63u;
+        double mega_ms = 0;
+        unsigned long long hstats[5] = {};
+        for (uint64_t p0 = 0; p0 < n_pix; p0 += pix_per_pass) {
+            const uint64_t np = std::min<uint64_t>(pix_per_pass, n_pix - p0);
+            const uint64_t total = np * (uint64_t)plan.spp;
+            ljd::DPass pass{};
+            pass.pixel_list = (const uint32_t *)ctx->pixel_list.p + p0; pass.n_pixels = (uint32_t)np; pass.spp = (uint32_t)plan.spp;
+            pass.seed = plan.seed; pass.sample_rgb = (float *)ctx->sample_rgb.p;
+            HIP_CHECK(hipMemsetAsync(ctx->mega_state.p, 0, 64, stream));
+            // persistent grid: as many workgroups as stay resident, but no more waves than there are `grab`-sized pieces of work
+            const uint64_t pieces = (total + grab - 1) / grab;
+            const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)ctx->n_cus * per_cu, (pieces + 3) / 4));
+            if (timing) HIP_CHECK(hipEventRecord(ctx->ev_k0, stream));
+            ljd::launch_mega(ds, pass, sc->scfg, sc->flat.n_spheres > 0, (uint32_t)total, grab, (uint32_t *)ctx->mega_state.p,
+                             (unsigned long long *)((char *)ctx->mega_state.p + 8), grid, stream);
+            HIP_CHECK(hipGetLastError());
+            if (timing) {
+                HIP_CHECK(hipEventRecord(ctx->ev_k1, stream)); HIP_CHECK(hipEventSynchronize(ctx->ev_k1));
+                float a = 0; HIP_CHECK(hipEventElapsedTime(&a, ctx->ev_k0, ctx->ev_k1)); mega_ms += a;
+            }
+            st.mega_launches++; st.wavefront_steps++;
+            if (rgb_dev) ljd::launch_resolve(pass, (uint32_t)np, rgb_dev, stream);
+            unsigned long long h[5];
+            HIP_CHECK(hipMemcpyAsync(h, (char *)ctx->mega_state.p + 8, sizeof(h), hipMemcpyDeviceToHost, stream));
+            if (samples_host) HIP_CHECK(hipMemcpyAsync(samples_host + p0 * (uint64_t)plan.spp * 3, ctx->sample_rgb.p, total * 12, hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+            if (h[3] != total)
+                throw LjError(LJ_ERR_INTERNAL, "mega launch ended with " + std::to_string(h[3]) + " of " + std::to_string(total) + " samples finished");
+            for (int k = 0; k < 5; k++) hstats[k] += h[k];
+            st.samples += total;
+        }
+        HIP_CHECK(hipEventRecord(ctx->ev_end, stream));
+        HIP_CHECK(hipEventSynchronize(ctx->ev_end));
+        float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
+        st.render_ms = ms; st.mega_ms = mega_ms;
+        st.bounce_iterations = hstats[0]; st.rays_closest = hstats[1]; st.rays_shadow = hstats[2]; st.path_steps = hstats[4];
+        // algorithmic HBM bytes of a mega launch: the finished radiance of every sample (12 B) and its pixel's list entry — the path state
+        // never leaves the registers
+        st.mega_bytes = st.samples * 12ull + n_pix * 4ull;
+        st.queue_bytes = st.mega_bytes;
+        return;
+    }
     // queue geometry: n_blocks workgroups x seg slots; workgroup b owns slots [b*seg, (b+1)*seg)
     const uint64_t pass_samples_max = pix_per_pass * (uint64_t)plan.spp;
     uint32_t pool = (uint32_t)std::min<uint64_t>(plan.pool, std::max<uint64_t>(pass_samples_max, 256));
@@ -293,6 +349,7 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
         st.samples += total;
         // algorithmic queue traffic per live path-step: extend reads ro, rd (32 B), rs (16 B) when a shadow ray
         // is pending, and writes rh (16 B); shade reads 7 records (112 B) and writes 7 (112 B), plus 12 B per finished sample
+        st.path_steps += path_steps;
         st.extend_bytes += path_steps * 48ull + shadow_rays * 16ull;
         st.shade_bytes += path_steps * 224ull + total * 12ull;
         // (both lanes were synchronised with the host above, so the caller's stream may read what the second lane wrote)
@@ -374,6 +431,7 @@ int lj_scene_upload(lj_context *ctx, const LjSceneDesc *desc, lj_scene **out) {
         upload(sc->light_tris, F.light_tris, s); upload(sc->light_tri_cdf, F.light_tri_cdf, s);
         upload(sc->images3, F.images3, s); upload(sc->images1, F.images1, s); upload(sc->texels, F.texels, s); upload(sc->env_tables, F.env_tables, s);
         upload(sc->media, F.media, s); upload(sc->volume_data, F.volume_data, s); upload(sc->shape_media, F.shape_media, s);
+        upload(sc->scan_leaves, F.scan_leaves, s);
         HIP_CHECK(hipStreamSynchronize(s));
         ljd::DScene d = F.host_view();
         d.nodes = (const ljd::DNode4 *)sc->nodes.p; d.leaf_prims = (const ljd::DPrim *)sc->leaf_prims.p; d.prims = (const ljd::DPrimShade *)sc->prims.p;
@@ -381,6 +439,7 @@ int lj_scene_upload(lj_context *ctx, const LjSceneDesc *desc, lj_scene **out) {
         d.light_cdf = (const float *)sc->light_cdf.p; d.light_tris = (const ljd::DLightTri *)sc->light_tris.p; d.light_tri_cdf = (const float *)sc->light_tri_cdf.p;
         d.images3 = (const ljd::DImage *)sc->images3.p; d.images1 = (const ljd::DImage *)sc->images1.p; d.texels = (const float *)sc->texels.p; d.env_tables = (const float *)sc->env_tables.p;
         d.media = (const ljd::DMedium *)sc->media.p; d.volume_data = (const float *)sc->volume_data.p; d.shape_media = (const int32_t *)sc->shape_media.p;
+        d.scan_leaves = F.scan_leaves.empty() ? nullptr : (const ljd::DScanLeaf *)sc->scan_leaves.p;
         sc->dscene = d;
         {   int64_t g = 0;
             for (int si = 0; si < desc->n_shapes; si++) { sc->shape_first_gprim.push_back(g); g += desc->shapes[si].kind == LJ_SHAPE_SPHERE ? 1 : desc->shapes[si].n_triangles; }
@@ -467,7 +526,11 @@ static int trace_batch(lj_scene *scene, int64_t n, const LjRay *rays_host, LjHit
         out.alloc((size_t)n * (hits_host ? sizeof(LjHit) : 1));
         HIP_CHECK(hipMemcpyAsync(rays.p, rays_host, (size_t)n * sizeof(LjRay), hipMemcpyHostToDevice, ctx->stream));
         int grid = (int)std::min<int64_t>((n + 255) / 256, ctx->n_cus * 4);
-        ljd::launch_trace_rays(scene->dscene, rays.p, n, hits_host ? out.p : nullptr, hits_host ? nullptr : (unsigned char *)out.p, scene->ecfg, ensure_spill(ctx, scene->ecfg.spill_levels, (uint32_t)grid), grid, ctx->stream);
+        // a tiny scene is traced by the leaf scan of mega.hip in a render, so that is what answers here too (LJ_TUNE_MEGA=0: the BVH
+        // traversal of k_extend, as for every other scene)
+        const bool scan = scene->dscene.n_scan_leaves > 0 && !(getenv("LJ_TUNE_MEGA") && atoi(getenv("LJ_TUNE_MEGA")) == 0);
+        if (scan) ljd::launch_trace_rays_scan(scene->dscene, rays.p, n, hits_host ? out.p : nullptr, hits_host ? nullptr : (unsigned char *)out.p, grid, ctx->stream);
+        else ljd::launch_trace_rays(scene->dscene, rays.p, n, hits_host ? out.p : nullptr, hits_host ? nullptr : (unsigned char *)out.p, scene->ecfg, ensure_spill(ctx, scene->ecfg.spill_levels, (uint32_t)grid), grid, ctx->stream);
         HIP_CHECK(hipGetLastError());
         if (hits_host) HIP_CHECK(hipMemcpyAsync(hits_host, out.p, (size_t)n * sizeof(LjHit), hipMemcpyDeviceToHost, ctx->stream));
         else HIP_CHECK(hipMemcpyAsync(occ_host, out.p, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));

@@ -6,6 +6,7 @@
 #include "../host/api_common.h"
 #include "../host/flatten.h"
 #include "dtypes.h"
+#include "dconfig.h"
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -14,8 +15,6 @@
 #include <vector>
 
 namespace ljd {
-struct ExtendConfig { int stack; int spill_levels; int lds_nodes; int lds_prims; int resident; int spheres; size_t smem; uint32_t refill_min, min_descending; };
-struct ShadeConfig { uint32_t prims_bytes, materials_bytes, lights_bytes, light_cdf_bytes, light_tris_bytes, light_tri_cdf_bytes, stage_prims; int variant; size_t smem; };
 ShadeConfig shade_config(size_t n_prims, size_t n_materials, size_t n_lights, size_t n_light_tris, size_t n_light_tri_cdf);
 int shade_variant(uint32_t kinds, bool textured, bool envmap, bool sphere_lights);
 ExtendConfig extend_config(int n_nodes, int n_prims, int bvh_depth, int n_spheres);
@@ -28,6 +27,11 @@ void launch_tail(const DScene &sc, const DPass &pass, const DQueue &q, DBlockSta
 void launch_aux(const DScene &sc, const uint32_t *pixel_list, uint32_t n_pixels, int integrator, float *rgb, const ExtendConfig &cfg, int *spill, int grid, hipStream_t s);
 void launch_volpath(const DScene &sc, const DPass &pass, uint32_t n_samples, unsigned long long *bounce_counter, const ExtendConfig &cfg, int *spill, int grid, hipStream_t s);
 void launch_trace_rays(const DScene &sc, const void *rays, long long n, void *hits, unsigned char *occ, const ExtendConfig &cfg, int *spill, int grid, hipStream_t s);
+// mega.hip
+size_t mega_smem(const DScene &sc, const ShadeConfig &scfg);
+int mega_blocks_per_cu(const ShadeConfig &scfg);
+void launch_mega(const DScene &sc, const DPass &pass, const ShadeConfig &scfg, bool spheres, uint32_t n_samples, uint32_t grab, uint32_t *sample_counter, unsigned long long *stats, int grid, hipStream_t s);
+void launch_trace_rays_scan(const DScene &sc, const void *rays, long long n, void *hits, unsigned char *occ, int grid, hipStream_t s);
 }
 
 using lj::LjError;
@@ -63,6 +67,7 @@ struct lj_context {
     DevBuf chunk_counter, chunk_list;  // the extend kernel's work counters and the two lists of live queue chunks
     DevBuf spill;  // overflow levels of the traversal stacks: spill_levels x (grid * 256) ints
     DevBuf blocks, sample_rgb, pixel_list, frame;
+    DevBuf mega_state;   // k_mega: [0] the grid-wide camera-sample counter (uint32), [8..] five 64-bit statistics
     ljd::DBlockState *blocks_host = nullptr;  // pinned, kMaxBlocks entries
     hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_k0 = nullptr, ev_k1 = nullptr;
 };
@@ -71,7 +76,7 @@ struct lj_scene {
     lj_context *ctx = nullptr;
     lj::FlatScene flat;  // host copy (tables for lj_scene_info; arrays already uploaded)
     DevBuf nodes, leaf_prims, prims, spheres, materials, lights, light_cdf, light_tris, light_tri_cdf, images3, images1, texels, env_tables;
-    DevBuf media, volume_data, shape_media;
+    DevBuf media, volume_data, shape_media, scan_leaves;
     ljd::DScene dscene{};
     ljd::ExtendConfig ecfg{};
     ljd::ShadeConfig scfg{};

@@ -1,0 +1,13 @@
+// Launch plans decided at scene upload (kernels.hip, mega.hip) and carried by the scene object (api_internal.h).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+namespace ljd {
+
+// LDS image of the extend kernel: stack levels, staged nodes / primitives, which instantiation
+struct ExtendConfig { int stack; int spill_levels; int lds_nodes; int lds_prims; int resident; int spheres; size_t smem; uint32_t refill_min, min_descending; };
+// LDS staging plan of the shade kernel (sizes rounded up to 16 bytes) and the feature-set instantiation (dshade.h)
+struct ShadeConfig { uint32_t prims_bytes, materials_bytes, lights_bytes, light_cdf_bytes, light_tris_bytes, light_tri_cdf_bytes, stage_prims; int variant; size_t smem; };
+
+} // namespace ljd

@@ -52,6 +52,11 @@ static_assert(sizeof(DPrimShade) == 112, "DPrimShade layout");
 
 struct DSphere { double center[3]; double radius; };
 
+// One leaf of a tiny scene's flat leaf table (dscan.h): padded box + its primitives [first, first + count) of the leaf-ordered
+// primitive array.  32 bytes: one s_load_dwordx8.
+struct DScanLeaf { float lo[3], hi[3]; int32_t first, count; };
+static_assert(sizeof(DScanLeaf) == 32, "DScanLeaf must be 32 bytes");
+
 struct DTexture {
     int32_t kind, texture_id;
     float value[3], color1[3];
@@ -131,6 +136,8 @@ struct DScene {
     const float *volume_data;
     const int32_t *shape_media;      // per shape: interior, exterior medium id (-1: none)
     int32_t cam_medium, max_null_collisions;
+    // tiny scenes only (dscan.h): the flat leaf table; n_scan_leaves is a multiple of 4, 0 when the scene has none
+    const DScanLeaf *scan_leaves; int32_t n_scan_leaves;
 };
 
 // ---- wavefront path queue: one slot per in-flight path, stored as eight arrays of 16-byte records so that every

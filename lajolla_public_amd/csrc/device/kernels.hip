@@ -18,18 +18,12 @@
 //   k_trace_rays             : batched intersect()/occluded() for the parity tests
 #include <hip/hip_runtime.h>
 #include <cstdlib>
-#include "dshade.h"
+#include "dstage.h"
 #include "dvol.h"
 #include "dtrace.h"
+#include "dconfig.h"
 
 namespace ljd {
-
-constexpr int kBlock = 256;
-#define LJ_LDS __attribute__((address_space(3)))
-typedef float v4f __attribute__((ext_vector_type(4)));  // builtin vector: assignable across address spaces
-
-__device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
-__device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
 
 // ---------------------------------------------------------------- queue <-> registers (16-byte records)
 __device__ __forceinline__ void q_load_for_shade(const DQueue &q, uint32_t i, PathState &ps) {
@@ -66,7 +60,6 @@ struct TreeView {
     uint32_t qstride;    // bytes between two quarters of one node in the LDS image (= staged nodes * 16)
 };
 
-extern __shared__ __attribute__((aligned(16))) v4f lj_smem[];
 
 __device__ __forceinline__ TreeView stage_tree(const DScene &sc, int stack, int lds_nodes, int lds_prims, int *spill, uint32_t spill_stride, uint32_t lane_global) {
     TreeView tv;
@@ -360,21 +353,6 @@ __global__ void __launch_bounds__(kBlock, (RESIDENT && !SPHERES && !STATS) ? LJ_
 }
 
 // ---------------------------------------------------------------- shade + compaction
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
-// The shading tables every path touches in a data-dependent order (per-primitive shading records, materials, lights
-// and their cdfs) are copied to LDS once per workgroup when they fit: a chain of five or six dependent L2-latency
-// gathers per path-step becomes LDS-latency reads.  Pointers stay generic, so dshade.h is unchanged.
-struct ShadeStage { uint32_t prims_bytes, materials_bytes, lights_bytes, light_cdf_bytes, light_tris_bytes, light_tri_cdf_bytes, stage_prims; };
-
-__device__ __forceinline__ void lds_copy16(void *dst, const void *src, uint32_t bytes) {
-    const v4f *s4 = (const v4f *)src; v4f *d4 = (v4f *)dst;
-    for (uint32_t i = threadIdx.x; i < bytes / 16; i += kBlock) d4[i] = s4[i];
-}
-
 // Shade the `count` live paths at the front of one segment chunk by chunk; survivors are compacted to the front, in
 // order (stable).  Returns the number of survivors (identical in every thread).  s_wcnt: 2 x (kBlock / 64) words of LDS.
 template <class Ft>
@@ -406,23 +384,6 @@ __device__ __forceinline__ uint32_t shade_compact_segment(const DScene &sc, cons
         out += total;
     }
     return out;
-}
-
-// LDS staging of the shading tables at byte offset `at` of the dynamic segment; rewrites the pointers of `sc`
-// STAGE — what the launch stages: 0 nothing (the tables do not fit, shade_config), 1 materials, lights and their cdfs,
-// 2 the per-primitive shading records as well, -1 decided at run time from `stg`.  With a compile-time STAGE the staged
-// pointers are LDS pointers by construction, which the compiler sees: their reads become ds_read instead of flat loads
-// (flat loads wait on the vector-memory counter together with the queue records).
-template <int STAGE>
-__device__ __forceinline__ void stage_shade_tables(DScene &sc, const ShadeStage &stg, uint32_t at) {
-    char *p = (char *)lj_smem + at;
-    if (STAGE == 0 || (STAGE < 0 && stg.materials_bytes == 0u)) return;   // the pointers stay global
-    if (STAGE == 2 || (STAGE < 0 && stg.stage_prims)) { lds_copy16(p, sc.prims, stg.prims_bytes); sc.prims = (const DPrimShade *)p; p += stg.prims_bytes; }
-    lds_copy16(p, sc.materials, stg.materials_bytes); sc.materials = (const DMaterial *)p; p += stg.materials_bytes;
-    lds_copy16(p, sc.lights, stg.lights_bytes); sc.lights = (const DLight *)p; p += stg.lights_bytes;
-    lds_copy16(p, sc.light_cdf, stg.light_cdf_bytes); sc.light_cdf = (const float *)p; p += stg.light_cdf_bytes;
-    lds_copy16(p, sc.light_tris, stg.light_tris_bytes); sc.light_tris = (const DLightTri *)p; p += stg.light_tris_bytes;
-    lds_copy16(p, sc.light_tri_cdf, stg.light_tri_cdf_bytes); sc.light_tri_cdf = (const float *)p;
 }
 
 // (the feature sets the shade kernel is compiled for — FeatLambert ... FeatAll — are listed in dshade.h)
@@ -652,7 +613,6 @@ __global__ void __launch_bounds__(kBlock) k_volpath(DScene sc, DPass pass, uint3
 // lane's stack live in LDS (1 KiB per level and workgroup); deeper levels — rare — go to a global overflow buffer.
 // LDS per 256-thread workgroup = stack * 1 KiB + staged nodes * 112 B + staged prims * 48 B; four workgroups share a
 // CU's 160 KiB, so the budget per workgroup is 40 KiB.
-struct ExtendConfig { int stack; int spill_levels; int lds_nodes; int lds_prims; int resident; int spheres; size_t smem; uint32_t refill_min, min_descending; };
 
 ExtendConfig extend_config(int n_nodes, int n_prims, int bvh_depth, int n_spheres) {
     ExtendConfig c;
@@ -685,7 +645,6 @@ ExtendConfig extend_config(int n_nodes, int n_prims, int bvh_depth, int n_sphere
 int max_stack_depth() { return 40; }  // inner levels; the builder's own cap is 38
 
 // LDS staging plan of the shade kernel; sizes are rounded up to 16 bytes (the device buffers are padded accordingly).
-struct ShadeConfig { uint32_t prims_bytes, materials_bytes, lights_bytes, light_cdf_bytes, light_tris_bytes, light_tri_cdf_bytes, stage_prims; int variant; size_t smem; };
 ShadeConfig shade_config(size_t n_prims, size_t n_materials, size_t n_lights, size_t n_light_tris, size_t n_light_tri_cdf) {
     auto r16 = [](size_t b) { return (uint32_t)((b + 15) & ~(size_t)15); };
     ShadeConfig c{};

@@ -80,6 +80,7 @@ ljd::DScene FlatScene::host_view() const {
     s.init_spread = 0.25f / (float)std::max(cam.width, cam.height);
     s.media = media.data(); s.n_media = (int)media.size(); s.volume_data = volume_data.data(); s.shape_media = shape_media.data();
     s.cam_medium = cam_medium; s.max_null_collisions = max_null_collisions;
+    s.scan_leaves = scan_leaves.empty() ? nullptr : scan_leaves.data(); s.n_scan_leaves = (int32_t)scan_leaves.size();
     return s;
 }
 
@@ -240,6 +241,24 @@ FlatScene flatten_scene(const LjSceneDesc &d) {
     build_bvh(bprims, max_leaf, 38, F.nodes, order, F.bvh_depth);
     F.leaf_prims.resize(gprims.size());
     for (size_t i = 0; i < order.size(); i++) F.leaf_prims[i] = gprims[order[i]];
+    // ---- flat leaf table of a tiny scene (device/dscan.h): the leaves of the tree with their (padded) boxes, one 32-byte
+    // record each, for the scan-based traversal that tests every leaf box of the scene for every ray (no stack, no node
+    // fetches, every lane busy).  Only for scenes of at most 32 leaves and 256 primitives; padded to a multiple of four with
+    // boxes that are never entered (a far-away point) and hold no primitive.
+    {
+        std::vector<ljd::DScanLeaf> leaves;
+        for (const auto &nd : F.nodes) for (int k = 0; k < 4; k++) {
+            if (nd.child[k] >= 0 || !(nd.lox[k] <= nd.hix[k])) continue;
+            ljd::DScanLeaf L{};
+            L.lo[0] = nd.lox[k]; L.lo[1] = nd.loy[k]; L.lo[2] = nd.loz[k]; L.hi[0] = nd.hix[k]; L.hi[1] = nd.hiy[k]; L.hi[2] = nd.hiz[k];
+            L.first = (~nd.child[k]) >> 3; L.count = ((~nd.child[k]) & 7) + 1;
+            leaves.push_back(L);
+        }
+        if (leaves.size() <= 32 && F.leaf_prims.size() <= 256 && !leaves.empty()) {
+            while (leaves.size() % 4) { ljd::DScanLeaf L{}; for (int k = 0; k < 3; k++) L.lo[k] = L.hi[k] = 1e18f; L.first = 0; L.count = 0; leaves.push_back(L); }
+            F.scan_leaves = leaves;
+        }
+    }
 
     // ---- lights
     std::vector<double> power(d.n_lights, 0.0);

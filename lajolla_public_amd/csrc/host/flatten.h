@@ -26,6 +26,7 @@ struct FlatScene {
     std::vector<ljd::DMedium> media;
     std::vector<float> volume_data;
     std::vector<int32_t> shape_media;
+    std::vector<ljd::DScanLeaf> scan_leaves;   // tiny scenes only (else empty): the flat leaf table of device/dscan.h
     int cam_medium = -1, max_null_collisions = 1000, vol_path_version = 0;
     int envmap_light_id = -1, max_depth = -1, rr_depth = 5, spp = 4, integrator = LJ_INTEGRATOR_PATH;
     int bvh_depth = 0;

@@ -31,7 +31,17 @@ struct HostMem {
 };
 
 // traversal work counters (debugging aid): [shadow rays, shadow nodes, shadow prims, ext rays, ext nodes, ext prims]
-static thread_local unsigned long long g_trav[6];
+static thread_local unsigned long long g_trav[8];
+// (developer aid) number of leaf boxes of the whole tree a ray segment overlaps: the candidate count of a flat leaf scan
+static int count_leaf_boxes(const DScene &sc, const RayF &ray) {
+    const float ix = 1.0f / ray.dx, iy = 1.0f / ray.dy, iz = 1.0f / ray.dz;
+    int n = 0;
+    for (int i = 0; i < sc.n_nodes; i++) for (int k = 0; k < 4; k++) {
+        if (sc.nodes[i].child[k] >= 0 || !(sc.nodes[i].lox[k] <= sc.nodes[i].hix[k])) continue;
+        float te; if (box_test4(sc.nodes[i], k, ray, ix, iy, iz, ray.tfar, te)) n++;
+    }
+    return n;
+}
 
 // what k_extend does for one queue slot
 void extend_one(const DScene &sc, PathState &ps) {
@@ -42,6 +52,7 @@ void extend_one(const DScene &sc, PathState &ps) {
         ray.dx = ps.sdir.x; ray.dy = ps.sdir.y; ray.dz = ps.sdir.z; ray.tnear = sc.eps; ray.tfar = ps.stfar;
         HitRec h;
         if (!traverse<true>(mem, ray, h)) code |= HIT_VIS_BIT;
+        if (getenv("LJ_TWIN_TRAV")) g_trav[6] += count_leaf_boxes(sc, ray);
         g_trav[0]++; g_trav[1] += mem.n_nodes; g_trav[2] += mem.n_prims; mem.n_nodes = mem.n_prims = 0;
     }
     float t = 0, u = 0, v = 0;
@@ -50,6 +61,7 @@ void extend_one(const DScene &sc, PathState &ps) {
         ray.tnear = ((ps.flags & 0xffffu) == 2u) ? 0.0f : sc.eps; ray.tfar = INFINITY;
         HitRec h;
         if (traverse<false>(mem, ray, h)) { code |= (h.gprim + 1); t = h.t; u = h.u; v = h.v; }
+        if (getenv("LJ_TWIN_TRAV")) g_trav[7] += count_leaf_boxes(sc, ray);
         g_trav[3]++; g_trav[4] += mem.n_nodes; g_trav[5] += mem.n_prims;
     }
     ps.ht = t; ps.hu = u; ps.hv = v; ps.hcode = code;
@@ -132,7 +144,7 @@ void twin_render_samples(void *tv, int spp, int max_depth, int use_max_depth, ui
             out[3 * s] = ps.rad.x; out[3 * s + 1] = ps.rad.y; out[3 * s + 2] = ps.rad.z;
         }
         bounces[tid] = cnt.bounces;
-        if (getenv("LJ_TWIN_TRAV")) fprintf(stderr, "trav[%d]: shadow rays %llu nodes/ray %.2f prims/ray %.2f | ext rays %llu nodes/ray %.2f prims/ray %.2f\n", tid, g_trav[0], g_trav[1] / (double)g_trav[0], g_trav[2] / (double)g_trav[0], g_trav[3], g_trav[4] / (double)g_trav[3], g_trav[5] / (double)g_trav[3]);
+        if (getenv("LJ_TWIN_TRAV")) fprintf(stderr, "trav[%d]: shadow rays %llu nodes/ray %.2f prims/ray %.2f | ext rays %llu nodes/ray %.2f prims/ray %.2f | flat-scan candidates: %.2f per shadow ray, %.2f per ext ray\n", tid, g_trav[0], g_trav[1] / (double)g_trav[0], g_trav[2] / (double)g_trav[0], g_trav[3], g_trav[4] / (double)g_trav[3], g_trav[5] / (double)g_trav[3], g_trav[6] / (double)g_trav[0], g_trav[7] / (double)g_trav[3]);
     };
     std::vector<std::thread> th;
     for (int i = 1; i < n_threads; i++) th.emplace_back(worker, i);
@@ -282,6 +294,17 @@ int twin_variant_covers(void *tv, int v) {
     for (const auto &m : t->flat.materials) { kinds |= 1u << m.kind; for (int k = 0; k < 12; k++) textured = textured || m.tex[k].kind != 0; }
     for (const auto &l : t->flat.lights) sphere_lights = sphere_lights || (l.kind == 0 && l.is_sphere);
     return variant_covers(v, kinds, textured, t->flat.envmap_light_id >= 0, sphere_lights) ? 1 : 0;
+}
+
+// BVH shape (developer aid): out[0] nodes, out[1] leaves, out[2] depth, out[3..10] leaves holding 1..8 primitives
+void twin_bvh_stats(void *tv, long long *out) {
+    Twin *t = (Twin *)tv;
+    for (int i = 0; i < 11; i++) out[i] = 0;
+    out[0] = (long long)t->flat.nodes.size(); out[2] = t->flat.bvh_depth;
+    for (const auto &nd : t->flat.nodes) for (int k = 0; k < 4; k++) {
+        if (!(nd.lox[k] <= nd.hix[k])) continue;   // empty slot
+        if (nd.child[k] < 0) { out[1]++; out[3 + ((~nd.child[k]) & 7)]++; }
+    }
 }
 
 void twin_intersect(void *tv, int64_t n, const LjRay *rays, LjHit *hits) {
