@@ -10,6 +10,7 @@ in this package: if the library is missing, or no gfx950 device is present, the 
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -116,12 +117,22 @@ class Context:
     def __init__(self, device=0):
         lib = load_library()
         self._h = C.c_void_p()
+        self._scenes = 0        # live Scene objects on this context
+        self._released = False  # __del__ has run while scenes were still alive: the last scene destroys the context
         _check(lib.lj_context_create(int(device), C.byref(self._h)))
 
-    def __del__(self):
-        if getattr(self, "_h", None) and _lib is not None:
+    def _destroy(self):
+        if getattr(self, "_h", None) and _lib is not None and not sys.is_finalizing():
             _lib.lj_context_destroy(self._h)
             self._h = None
+
+    def __del__(self):
+        # A scene keeps its context alive by reference, but when both die in one garbage-collected cycle (a failed test's
+        # traceback holds them) Python may finalise the context first: it must then outlive the scenes at the C level.
+        if getattr(self, "_scenes", 0) > 0:
+            self._released = True
+        else:
+            self._destroy()
 
 
 class Scene:
@@ -133,14 +144,18 @@ class Scene:
         self._h = C.c_void_p()
         desc_ptr = host_scene_or_desc.desc_ptr if isinstance(host_scene_or_desc, HostScene) else C.pointer(host_scene_or_desc)
         _check(lib.lj_scene_upload(ctx._h, desc_ptr, C.byref(self._h)))
+        ctx._scenes += 1
         info = LjSceneInfo()
         _check(lib.lj_scene_info(self._h, C.byref(info)))
         self.info = info
 
     def __del__(self):
-        if getattr(self, "_h", None) and _lib is not None:
+        if getattr(self, "_h", None) and _lib is not None and not sys.is_finalizing():
             _lib.lj_scene_destroy(self._h)
             self._h = None
+            self._ctx._scenes -= 1
+            if self._ctx._released and self._ctx._scenes == 0:
+                self._ctx._destroy()
 
     def stats(self):
         st = LjStats()

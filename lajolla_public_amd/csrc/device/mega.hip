@@ -74,6 +74,9 @@ __device__ __forceinline__ uint32_t scan_leaf_boxes(const ScanCtx &sx, f3 org, f
 template <bool SPHERES>
 __device__ __forceinline__ void scan_trace(const ScanCtx &sx, bool has_e, bool has_s, f3 org, f3 dir_e, float tnear_e, f3 dir_s, float tnear_s, float tfar_s,
                                            float &ht, float &hu, float &hv, int &gprim_out, bool &occluded) {
+    // No floating-point contraction in here: u = U * (1 / S) must reach the shading code as the rounded product k_extend stores in
+    // the hit record, not as a multiply the compiler may fuse into the consumer's `1 - u - v` (a 1-ulp difference in 1e-4 of the samples).
+#pragma clang fp contract(off)
     const uint32_t lane = lane_id();
     uint32_t me = 0, ms = 0;
     if (__ballot(has_e) != 0ull) { me = scan_leaf_boxes(sx, org, dir_e, tnear_e, INFINITY); me = has_e ? me : 0u; }
@@ -159,6 +162,24 @@ __device__ __forceinline__ void scan_trace(const ScanCtx &sx, bool has_e, bool h
     }
 }
 
+// a + b of two values that are each already rounded: the wavefront kernels add the next-event contribution after it has been through
+// the queue, so the product that formed it must not be fused into this addition
+__device__ __forceinline__ f3 add_rounded(f3 a, f3 b) {
+#pragma clang fp contract(off)
+    return mk3(a.x + b.x, a.y + b.y, a.z + b.z);
+}
+
+// The wavefront kernels hand a path from one step to the next through the queue, so every value shade_path receives is a rounded
+// float the compiler knows nothing about.  Here the same values stay in registers across the loop; without this fence the optimiser
+// may fuse the multiply that produced one of them into an addition that consumes it in the next step (a 1-ulp difference in one
+// sample of 10^4).  An empty asm per field makes each an opaque register value: no instruction is emitted.
+__device__ __forceinline__ void opaque(float &x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void opaque(f3 &v) { opaque(v.x); opaque(v.y); opaque(v.z); }
+__device__ __forceinline__ void opaque_state(PathState &ps) {
+    opaque(ps.org); opaque(ps.dir); opaque(ps.ht); opaque(ps.hu); opaque(ps.hv); opaque(ps.sdir); opaque(ps.stfar);
+    opaque(ps.W); opaque(ps.rr); opaque(ps.p2); opaque(ps.rad); opaque(ps.nee); opaque(ps.eta_scale); opaque(ps.spread);
+}
+
 // LDS image of the scan area at byte offset `at` (16-byte aligned): [leaf table][primitives, transposed][4 x wave scratch]
 __device__ __forceinline__ ScanCtx stage_scan(const DScene &sc, uint32_t at) {
     ScanCtx sx;
@@ -202,6 +223,7 @@ __global__ void __launch_bounds__(kBlock, MegaOccupancy<Ft>::waves) k_mega(DScen
     ps.flags = 0u; ps.stfar = 0.0f; ps.sample = 0u;
     for (;;) {
         // ---- the step of a path that is under way: hit accounting, next-event estimation, BSDF sampling (path_tracing.h:58-322)
+        opaque_state(ps);
         if (live) {
             steps++;
             if (!shade_path<Ft>(sc, pass, ps, cnt)) {
@@ -229,11 +251,12 @@ __global__ void __launch_bounds__(kBlock, MegaOccupancy<Ft>::waves) k_mega(DScen
         }
         if (__ballot(live) == 0ull) { if (exhausted) break; else continue; }
         // ---- both rays of the vertex: the pending shadow ray [eps, (1 - eps) d] and the extension ray [eps, inf) (camera rays from 0)
+        opaque_state(ps);
         const bool has_e = live && !(ps.flags & PF_NO_EXT), has_s = live && ps.stfar > 0.0f;
         float ht, hu, hv; int gprim; bool occluded;
         scan_trace<SPHERES>(sx, has_e, has_s, ps.org, ps.dir, (ps.flags & 0xffffu) == 2u ? 0.0f : sc.eps, ps.sdir, sc.eps, ps.stfar, ht, hu, hv, gprim, occluded);
         if (live) {
-            if (has_s && !occluded) ps.rad = ps.rad + ps.nee;   // path_tracing.h:207 (k_shade adds it at the top of the next step)
+            if (has_s && !occluded) ps.rad = add_rounded(ps.rad, ps.nee);   // path_tracing.h:207 (k_shade adds it at the top of the next step)
             ps.ht = ht; ps.hu = hu; ps.hv = hv; ps.hcode = gprim + 1;
             if (ps.flags & PF_NO_EXT) {   // sample_bsdf failed (path_tracing.h:220-223): nothing left but the contribution just added
                 float *o = pass.sample_rgb + 3ull * ps.sample;

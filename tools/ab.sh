@@ -13,6 +13,6 @@ for round in 1 2; do
 import sys, json
 d = json.loads(sys.stdin.readline())
 k = d['roofline']['all_kernels']
-print('$v round $round: %.2f ms/render  %.0f Msamples/s | 1-lane kernels: extend %.2f ms shade %.2f ms' % (d['ms_per_step'], d['value'], k['k_extend']['total_ms'], k['k_shade']['total_ms']))" || echo "$v FAILED"
+print('$v round $round: %.2f ms/render  %.0f Msamples/s | kernels alone: %s' % (d['ms_per_step'], d['value'], ', '.join('%s %.2f ms' % (n, x['total_ms']) for n, x in k.items())))" || echo "$v FAILED"
   done
 done
