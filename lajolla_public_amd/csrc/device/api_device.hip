@@ -208,7 +208,7 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
     uint32_t n_lanes = (timing || xstats || pool < (1u << 20)) ? 1u : (pool < (1u << 22) ? 2u : 4u);
     // the all-features shade kernel (164 VGPRs, three waves per SIMD) leaves an extend kernel no registers to run beside
     // it: lanes would only time-slice the GPU (disney_bsdf +6 %, disney_bsdf_array +12 % with four lanes)
-    if (sc->scfg.variant >= 3) n_lanes = 1;
+    if (sc->scfg.variant >= 3) n_lanes = 1;   // (FeatDisney, FeatAll)
     if (const char *e = getenv("LJ_TUNE_LANES")) n_lanes = (uint32_t)std::min((int)kMaxLanes, std::max(1, atoi(e)));
     uint32_t n_blocks = std::min<uint32_t>(kMaxBlocks, std::max<uint32_t>(n_lanes, std::min<uint32_t>((uint32_t)ctx->n_cus * blocks_per_cu, pool / 256)));
     n_blocks = (n_blocks / n_lanes) * n_lanes;
@@ -458,7 +458,7 @@ int lj_scene_upload(lj_context *ctx, const LjSceneDesc *desc, lj_scene **out) {
             sc->feat_kinds = kinds; sc->feat_textured = textured; sc->feat_envmap = F.envmap_light_id >= 0; sc->feat_sphere_lights = sphere_lights;
             sc->scfg.variant = ljd::shade_variant(kinds, textured, F.envmap_light_id >= 0, sphere_lights);
             if (const char *e = getenv("LJ_TUNE_SHADE_VARIANT")) sc->scfg.variant = std::max(sc->scfg.variant, atoi(e));
-            if (sc->scfg.smem == 0) sc->scfg.variant = 3;   // tables too large to stage: one instantiation serves that case
+            if (sc->scfg.smem == 0) sc->scfg.variant = ljd::kShadeVariantAll;   // tables too large to stage: one instantiation serves that case
         }
         *out = sc.release();
     });

@@ -5,6 +5,10 @@
 
 namespace ljd {
 
+// feature-set instantiations of the shading code (dshade.h lists them, smallest first)
+constexpr int kNumShadeVariants = 5;
+constexpr int kShadeVariantAll = kNumShadeVariants - 1;
+
 // LDS image of the extend kernel: stack levels, staged nodes / primitives, which instantiation
 struct ExtendConfig { int stack; int spill_levels; int lds_nodes; int lds_prims; int resident; int spheres; size_t smem; uint32_t refill_min, min_descending; };
 // LDS staging plan of the shade kernel (sizes rounded up to 16 bytes) and the feature-set instantiation (dshade.h)

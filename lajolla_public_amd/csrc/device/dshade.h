@@ -4,6 +4,7 @@
 // CPU-side debugging of the very same source, by g++ in tests/twin (never shipped, never a fallback).
 #pragma once
 #include "dmath.h"
+#include "dconfig.h"
 
 namespace ljd {
 
@@ -25,13 +26,15 @@ using FeatAll = ShadeFeat<0x1ffu, true, true, true>;
 using FeatLambert = ShadeFeat<0x001u, false, false, false>;      // constant-colour diffuse surfaces, mesh lights (cbox)
 using FeatLambertTex = ShadeFeat<0x001u, true, false, true>;     // + image / checker textures, sphere lights (sponza)
 using FeatClassic = ShadeFeat<0x007u, true, true, true>;         // diffuse, roughplastic, roughdielectric + everything else
-constexpr int kNumShadeVariants = 4;
+using FeatDisney = ShadeFeat<0x101u, true, true, false>;         // diffuse + the Disney principled BSDF, textures, environment map (disney_bsdf.xml)
+// (kNumShadeVariants = 5 and kShadeVariantAll, the index of the one that covers everything, live in dconfig.h)
 // calls fn(Feat{}) for variant v
 template <class Fn> inline void with_shade_variant(int v, Fn &&fn) {
     switch (v) {
         case 0: fn(FeatLambert{}); break;
         case 1: fn(FeatLambertTex{}); break;
         case 2: fn(FeatClassic{}); break;
+        case 3: fn(FeatDisney{}); break;
         default: fn(FeatAll{}); break;
     }
 }

@@ -648,12 +648,12 @@ int max_stack_depth() { return 40; }  // inner levels; the builder's own cap is 
 ShadeConfig shade_config(size_t n_prims, size_t n_materials, size_t n_lights, size_t n_light_tris, size_t n_light_tri_cdf) {
     auto r16 = [](size_t b) { return (uint32_t)((b + 15) & ~(size_t)15); };
     ShadeConfig c{};
-    c.variant = 3;
+    c.variant = kShadeVariantAll;
     c.materials_bytes = r16(n_materials * sizeof(DMaterial)); c.lights_bytes = r16(n_lights * sizeof(DLight));
     c.light_cdf_bytes = r16((n_lights + 1) * 4); c.light_tris_bytes = r16(n_light_tris * sizeof(DLightTri)); c.light_tri_cdf_bytes = r16(n_light_tri_cdf * 4);
     size_t small = (size_t)c.materials_bytes + c.lights_bytes + c.light_cdf_bytes + c.light_tris_bytes + c.light_tri_cdf_bytes;
     if (small > 24 * 1024) {  // too many materials / emissive triangles: leave everything in global memory
-        c = ShadeConfig{}; c.variant = 3; c.smem = 0; return c;
+        c = ShadeConfig{}; c.variant = kShadeVariantAll; c.smem = 0; return c;
     }
     c.prims_bytes = r16(n_prims * sizeof(DPrimShade));
     c.stage_prims = (small + c.prims_bytes <= 32 * 1024) ? 1u : 0u;
@@ -689,19 +689,13 @@ void launch_shade(const DScene &sc, const DPass &pass, const DQueue &q, DBlockSt
     st.prims_bytes = cfg.prims_bytes; st.materials_bytes = cfg.materials_bytes; st.lights_bytes = cfg.lights_bytes; st.light_cdf_bytes = cfg.light_cdf_bytes;
     st.light_tris_bytes = cfg.light_tris_bytes; st.light_tri_cdf_bytes = cfg.light_tri_cdf_bytes; st.stage_prims = cfg.stage_prims;
     auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(n_blocks), dim3(kBlock), cfg.smem, s, sc, pass, q, blocks, seg, st, work, chunk_list, parity, extend_waves); };
-    // (a scene whose tables are not staged at all runs the all-features instantiation: lj_scene_upload sets variant 3)
+    // (a scene whose tables are not staged at all runs the all-features instantiation: lj_scene_upload picks it)
     const int stage = cfg.smem == 0 ? 0 : (cfg.stage_prims ? 2 : 1);
-    switch (stage == 0 ? 30 : cfg.variant * 10 + stage) {
-        case 1: launch(k_shade<FeatLambert, 1>); break;
-        case 2: launch(k_shade<FeatLambert, 2>); break;
-        case 11: launch(k_shade<FeatLambertTex, 1>); break;
-        case 12: launch(k_shade<FeatLambertTex, 2>); break;
-        case 21: launch(k_shade<FeatClassic, 1>); break;
-        case 22: launch(k_shade<FeatClassic, 2>); break;
-        case 31: launch(k_shade<FeatAll, 1>); break;
-        case 32: launch(k_shade<FeatAll, 2>); break;
-        default: launch(k_shade<FeatAll, 0>); break;
-    }
+    if (stage == 0) { launch(k_shade<FeatAll, 0>); return; }
+    with_shade_variant(cfg.variant, [&](auto ft) {
+        using Ft = decltype(ft);
+        if (stage == 2) launch(k_shade<Ft, 2>); else launch(k_shade<Ft, 1>);
+    });
 }
 // LDS the fused tail needs: the extend image followed by the shade tables; 0 when that does not fit one workgroup's share
 size_t tail_smem(const ExtendConfig &ecfg, const ShadeConfig &scfg) {
@@ -715,12 +709,7 @@ void launch_tail(const DScene &sc, const DPass &pass, const DQueue &q, DBlockSta
     const uint32_t at = (uint32_t)((ecfg.smem + 15) & ~(size_t)15);
     const size_t smem = tail_smem(ecfg, scfg);
     auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(n_blocks), dim3(kBlock), smem, s, sc, pass, q, blocks, seg, st, at, ecfg.stack, ecfg.lds_nodes, ecfg.lds_prims, spill); };
-    switch (scfg.variant) {
-        case 0: launch(k_tail<FeatLambert>); break;
-        case 1: launch(k_tail<FeatLambertTex>); break;
-        case 2: launch(k_tail<FeatClassic>); break;
-        default: launch(k_tail<FeatAll>); break;
-    }
+    with_shade_variant(scfg.variant, [&](auto ft) { launch(k_tail<decltype(ft)>); });
 }
 void launch_resolve(const DPass &pass, uint32_t n_pixels, float *rgb, hipStream_t s) {
     const uint32_t waves_per_block = kBlock / 64;

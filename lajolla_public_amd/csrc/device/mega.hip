@@ -199,10 +199,12 @@ __device__ __forceinline__ ScanCtx stage_scan(const DScene &sc, uint32_t at) {
 }
 size_t scan_smem(int n_scan_leaves, int n_prims) { return (((size_t)n_scan_leaves * 8 + 15) & ~(size_t)15) + (size_t)n_prims * 48 + 4 * (size_t)kWaveScanBytes; }
 
-// waves per SIMD the kernel is built for: the Lambert-only instantiation needs 113 VGPRs (four waves, no scratch); the feature
-// sets with textures, microfacet lobes or sphere lights need ~150 and would spill 25-70 registers at four, so they get three
+// waves per SIMD the kernel is built for.  The Lambert-only instantiation needs 113 VGPRs unconstrained; built for five waves (96
+// VGPRs, 7 of them spilled to scratch) it is 7 % faster than for four — the kernel waits on LDS round trips and dependent issue,
+// which a fifth wave hides (measured on MI355X, cbox 256 spp: 3 waves 17.8 ms, 4: 16.1, 5: 14.9, 6: 15.7 with 43 spills).  The
+// feature sets with textures, microfacet lobes or sphere lights need ~150 VGPRs and spill 25-70 registers already at four: three.
 #ifndef LJ_MEGA_OCC
-#define LJ_MEGA_OCC 4
+#define LJ_MEGA_OCC 5
 #endif
 template <class Ft> struct MegaOccupancy { static constexpr int waves = 3; };
 template <> struct MegaOccupancy<FeatLambert> { static constexpr int waves = LJ_MEGA_OCC; };

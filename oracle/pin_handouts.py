@@ -1,0 +1,147 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE (build container only) — pins the integrators END TO END to the renders the reference itself holds.
+
+The reference cannot be linked here (Embree's Linux binary is absent), so no image can be produced from it; but its handouts
+carry images the reference rendered of its own shipped scenes (handouts/imgs/*.png: cbox, veach_mis, sponza, matpreview, the Disney
+BSDF gallery, the volumetric test scenes volpath_1..6, hetvol, colored_smoke, and the pixel-filter comparison box / tent /
+gaussian).  They are the only end-to-end outputs of path_tracing.h:7-325, vol_path_tracing.h:6-869 and the Embree traversal that
+exist.  This script
+
+  1. linearises each PNG (inverse sRGB transfer), averages it over 16x16-pixel blocks and marks the blocks that hold a clipped
+     (>= 250/255) pixel or are darker than 1/255 (8-bit quantisation dominates there) as unusable;
+  2. renders the same scene file with the CPU oracle (oracle/lj_oracle.cpp) at a high sample count, fits ONE exposure scalar per
+     image (least squares over the usable blocks) and measures the remaining per-block relative differences;
+  3. writes tests/golden/handouts.npz (the block means of the reference's images + masks) and tests/golden/handouts.json
+     (per image: scene file, overrides, fitted scalar, the measured differences and the tolerances the tests use).
+
+tests/test_handout_renders.py then holds the oracle (CPU suite, low sample counts) and the GPU renderer (`-m gpu`, high sample
+counts) to those fixtures.  Only data derived from the images is committed: block means, never the images.
+
+    python oracle/pin_handouts.py            # ~15 min on 8 cores
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+REF_IMGS = os.path.join(os.environ.get("LJ_REFERENCE_ROOT", "/root/reference"), "handouts", "imgs")
+BLOCK = 16
+
+# fixture name -> (handout image, scene file under scenes/, oracle spp for the fit, overrides)
+#   overrides: "filter": (kind, param) replaces the scene's pixel filter (the handout shows one scene under three filters, homework0.tex:238-260);
+#              "down": the handout is `down` times the scene's resolution (averaged down in linear space)
+PAIRS = {
+    "cbox": ("cbox.png", "cbox/cbox.xml", 256, {}),
+    "veach_mis": ("veach_mis.png", "veach_mi/mi.xml", 256, {}),
+    "sponza": ("sponza.png", "sponza/sponza.xml", 64, {}),
+    "matpreview": ("matpreview.png", "matpreview/matpreview.xml", 64, {}),
+    "disney_bsdf": ("disney_bsdf.png", "disney_bsdf_test/disney_bsdf.xml", 64, {"down": 2}),
+    "disney_diffuse": ("disney_diffuse.png", "disney_bsdf_test/disney_diffuse.xml", 64, {}),
+    "disney_metal": ("disney_metal.png", "disney_bsdf_test/disney_metal.xml", 64, {}),
+    "disney_clearcoat": ("disney_clearcoat.png", "disney_bsdf_test/disney_clearcoat.xml", 64, {}),
+    "disney_glass": ("disney_glass.png", "disney_bsdf_test/disney_glass.xml", 64, {}),
+    "disney_sheen": ("disney_sheen.png", "disney_bsdf_test/disney_sheen.xml", 64, {}),
+    "filter_box": ("box.png", "pixel_filter_test/pixel_filter_test.xml", 256, {"filter": (0, 1.0)}),
+    "filter_tent": ("tent.png", "pixel_filter_test/pixel_filter_test.xml", 256, {"filter": (1, 2.0)}),
+    "filter_gaussian": ("gaussian.png", "pixel_filter_test/pixel_filter_test.xml", 256, {"filter": (2, 0.75)}),
+    "volpath_1": ("volpath_1.png", "volpath_test/volpath_test1.xml", 256, {}),
+    "volpath_2": ("volpath_2.png", "volpath_test/volpath_test2.xml", 256, {}),
+    "volpath_3": ("volpath_3.png", "volpath_test/volpath_test3.xml", 256, {}),
+    "volpath_4": ("volpath_4.png", "volpath_test/volpath_test4.xml", 256, {}),
+    "volpath_4_2": ("volpath_4_2.png", "volpath_test/volpath_test4_2.xml", 256, {}),
+    "volpath_5": ("volpath_5.png", "volpath_test/volpath_test5.xml", 256, {}),
+    "volpath_5_2": ("volpath_5_2.png", "volpath_test/volpath_test5_2.xml", 256, {}),
+    "volpath_5_cbox": ("volpath_5_cbox.png", "volpath_test/vol_cbox.xml", 128, {}),
+    "volpath_5_cbox_teapot": ("volpath_5_cbox_teapot.png", "volpath_test/vol_cbox_teapot.xml", 64, {}),
+    "volpath_6": ("volpath_6.png", "volpath_test/volpath_test6.xml", 256, {}),
+    "hetvol": ("hetvol.png", "volpath_test/hetvol.xml", 64, {}),
+    "colored_smoke": ("colored_smoke.png", "volpath_test/hetvol_colored.xml", 64, {}),
+}
+
+
+def srgb_to_linear(a):
+    return np.where(a <= 0.04045, a / 12.92, ((a + 0.055) / 1.055) ** 2.4)
+
+
+def block_means(img, b=BLOCK):
+    h, w = img.shape[:2]
+    H, W = h // b, w // b
+    return img[:H * b, :W * b].reshape(H, b, W, b, -1).mean(axis=(1, 3))
+
+
+def load_handout(png, down=1):
+    """-> (linear block means (H, W, 3) float32, usable mask (H, W) bool)"""
+    from PIL import Image
+    raw = np.asarray(Image.open(png).convert("RGB"), dtype=np.float64) / 255.0
+    lin = srgb_to_linear(raw)
+    if down > 1:
+        h, w, _ = lin.shape
+        lin = lin.reshape(h // down, down, w // down, down, 3).mean(axis=(1, 3))
+        raw = raw.reshape(h // down, down, w // down, down, 3).max(axis=(1, 3))
+    means = block_means(lin)
+    clipped = block_means((raw >= 250.0 / 255.0).any(axis=-1, keepdims=True).astype(float))[..., 0] > 0
+    dark = means.max(axis=-1) < srgb_to_linear(np.float64(1.0 / 255.0)) * 4
+    return means.astype(np.float32), ~(clipped | dark)
+
+
+def apply_overrides(hs, ov):
+    if "filter" in ov:
+        hs.desc.camera.filter_kind, hs.desc.camera.filter_param = ov["filter"]
+
+
+def block_stats(handout, usable, render_blocks, s=None):
+    """One exposure scalar (fitted when s is None), then per-block relative differences over the usable blocks."""
+    x, y = handout[usable].astype(np.float64).ravel(), render_blocks[usable].astype(np.float64).ravel()
+    if s is None:
+        s = float((x * y).sum() / (x * x).sum())
+    rel = np.abs(s * handout[usable].astype(np.float64) - render_blocks[usable]).max(axis=-1) / np.maximum(render_blocks[usable].max(axis=-1), 1e-3)
+    return {"s": s, "median": float(np.median(rel)), "p90": float(np.percentile(rel, 90)), "rel_l2": float(np.linalg.norm(s * x - y) / np.linalg.norm(y)),
+            "mean_ratio": float((s * x).mean() / y.mean())}
+
+
+def main():
+    import lajolla_public_amd as lj
+    from helpers import Oracle
+    only = sys.argv[1:]
+    arrays, meta = {}, {"generator": "oracle/pin_handouts.py: handouts/imgs/*.png linearised (inverse sRGB), 16x16 block means; one exposure "
+                                      "scalar per image fitted against the CPU oracle at `spp`", "block": BLOCK, "images": {}}
+    out_npz, out_json = os.path.join(ROOT, "tests", "golden", "handouts.npz"), os.path.join(ROOT, "tests", "golden", "handouts.json")
+    if only and os.path.exists(out_npz):   # refresh some entries, keep the rest
+        arrays = dict(np.load(out_npz))
+        meta = json.load(open(out_json))
+    for name, (png, xml, spp, ov) in PAIRS.items():
+        if only and name not in only:
+            continue
+        handout, usable = load_handout(os.path.join(REF_IMGS, png), ov.get("down", 1))
+        hs = lj.parse_scene(os.path.join(ROOT, "scenes", xml))
+        apply_overrides(hs, ov)
+        o = Oracle(hs)
+        o.use_bvh(True)
+        t0 = time.time()
+        rc, rgb, _, st = o.render(spp=spp, rng_mode=0, threads=0)
+        assert rc == 0 and rgb.shape[:2] == (hs.height, hs.width)
+        rb = block_means(rgb)
+        assert rb.shape == handout.shape, (name, rb.shape, handout.shape)
+        fit = block_stats(handout, usable, rb)
+        # what a second, independent oracle render of the same spp differs from the first by: the noise floor of the comparison
+        rc, rgb2, _, _ = o.render(spp=spp, rng_mode=0, threads=0, seed=0x1234567)
+        noise = block_stats(rb.astype(np.float32), usable, block_means(rgb2), s=1.0)
+        arrays[name + "/blocks"], arrays[name + "/usable"] = handout, usable
+        meta["images"][name] = {"handout": "handouts/imgs/" + png, "scene": xml, "overrides": {k: list(v) if isinstance(v, tuple) else v for k, v in ov.items()},
+                                "fit_spp": spp, "exposure_scalar": round(fit["s"], 5), "usable_fraction": round(float(usable.mean()), 4),
+                                "oracle_vs_handout": {k: round(v, 5) for k, v in fit.items() if k != "s"},
+                                "oracle_vs_oracle_noise": {k: round(v, 5) for k, v in noise.items() if k != "s"}}
+        print(f"{name:24s} spp {spp:4d} {time.time() - t0:6.1f}s usable {usable.mean():.2f} s={fit['s']:.4f} median {fit['median']:.4f} p90 {fit['p90']:.4f} "
+              f"L2 {fit['rel_l2']:.4f} mean ratio {fit['mean_ratio']:.4f} | noise median {noise['median']:.4f} p90 {noise['p90']:.4f}", flush=True)
+    np.savez_compressed(out_npz, **arrays)
+    json.dump(meta, open(out_json, "w"), indent=1, sort_keys=True)
+    print("wrote", out_npz, out_json)
+
+
+if __name__ == "__main__":
+    main()

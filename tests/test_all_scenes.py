@@ -1,4 +1,4 @@
-"""Every scene file the reference ships (24 Mitsuba XMLs: path, direct, volpath with all six `version`s, every Material
+"""Every scene file the reference ships (25 Mitsuba XMLs: path, direct, volpath with all six `version`s, every Material
 alternative, sphere and mesh lights, environment maps, image / checker textures, heterogeneous media) must parse, upload and
 render, and the device code must follow the oracle under identical pcg32 streams on a window at the image centre.
 This sweep is what caught the two float-precision traps documented in dshade.h (LightSample::dpos, GTR2)."""
@@ -33,7 +33,7 @@ def check(name, got, ref):
 
 
 def test_the_sweep_covers_the_reference_scene_tree():
-    assert len(SCENES) == 24 and "volpath_test/hetvol_colored.xml" in SCENES and "matpreview/matpreview.xml" in SCENES
+    assert len(SCENES) == 25 and "pixel_filter_test/pixel_filter_test.xml" in SCENES and "volpath_test/hetvol_colored.xml" in SCENES and "matpreview/matpreview.xml" in SCENES
 
 
 @pytest.mark.parametrize("name", SCENES)
