@@ -317,6 +317,30 @@ typedef struct LjSceneInfo {
 } LjSceneInfo;
 int lj_scene_info(const lj_scene *scene, LjSceneInfo *out);
 
+/* ---------------------------------------------------------------- device groups: one process, N devices
+ * The reference's data-parallel axis is its tile loop (render.cpp:75-98 on parallel.cpp:183-237: independent 16x16 tiles, disjoint
+ * pixel writes).  A group shards that loop over devices from one host process: tile t = ty*ntx + tx goes to device t mod N, every
+ * device renders its tiles at full spp into a zeroed full frame, one ncclReduce(sum, root 0) of the float frames over xGMI, one
+ * copy to the host.  Each pixel has one non-zero contributor, so the image is bit-identical to a one-device render.
+ * (The process-per-GPU route — LjRenderArgs.rank / world_size + the caller's own collective — stays available: bench.py.)
+ *
+ * device_ids: n_devices HIP device ids (NULL: 0..n-1).  Ids may repeat ("logical ranks" on one GPU: same sharding, frames summed by
+ * a device kernel, since RCCL refuses duplicate devices).  RCCL (librccl.so) is bound at run time, only for >= 2 distinct devices. */
+typedef struct lj_device_group lj_device_group;
+typedef struct lj_group_scene lj_group_scene;
+int lj_group_create(int n_devices, const int *device_ids, lj_device_group **out);
+void lj_group_destroy(lj_device_group *group);
+int lj_group_size(const lj_device_group *group);
+lj_context *lj_group_context(lj_device_group *group, int i);     /* borrowed: device i's context */
+int lj_group_uses_rccl(const lj_device_group *group);             /* 1: the frames are reduced by ncclReduce, 0: by a device-side sum */
+/* Scene::Scene (scene.cpp:3-53) on every device of the group; the description may be freed afterwards. */
+int lj_group_scene_upload(lj_device_group *group, const LjSceneDesc *desc, lj_group_scene **out);
+void lj_group_scene_destroy(lj_group_scene *scene);
+lj_scene *lj_group_scene_member(lj_group_scene *scene, int i);   /* borrowed: the scene on device i */
+/* Replaces `Image3 render(const Scene&)` (render.h:9) across the group.  args->rank / world_size must be 0 (the group shards). */
+int lj_group_render(lj_group_scene *scene, const LjRenderArgs *args, float *rgb_host);
+int lj_group_get_stats(const lj_group_scene *scene, LjStats *out);   /* sums over the shares; render_ms is the slowest share's */
+
 /* imwrite() (image.h:46, image.cpp:135-173), host only: writes a width x height RGB float image (row-major, y = 0 at the
  * top) by extension — ".pfm": "PF", "<w> <h>", "-1", then the rows top to bottom as little-endian float (the
  * reference's layout, image.cpp:141-149); ".exr": scan-line OpenEXR, HALF channels B, G, R (what the reference asks

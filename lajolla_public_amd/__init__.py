@@ -325,3 +325,63 @@ def frame_queries(ctx, queries):
     r = np.zeros(q.shape[0], FRAME_RESULT)
     _check(load_library().lj_frame_queries(ctx._h, q.shape[0], _vp(q), _vp(r)))
     return r
+
+
+# ------------------------------------------------------------------ device groups: one process, N devices (lajolla_hip.h)
+class DeviceGroup:
+    """N devices driven from this process; RCCL communicator inside when they are distinct and N >= 2."""
+
+    def __init__(self, device_ids):
+        ids = (C.c_int * len(device_ids))(*[int(d) for d in device_ids])
+        self._h = C.c_void_p()
+        self._scenes = 0
+        self._released = False
+        _check(load_library().lj_group_create(len(device_ids), ids, C.byref(self._h)))
+        self.size = load_library().lj_group_size(self._h)
+        self.uses_rccl = bool(load_library().lj_group_uses_rccl(self._h))
+
+    def _destroy(self):
+        if getattr(self, "_h", None) and _lib is not None and not sys.is_finalizing():
+            _lib.lj_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        if getattr(self, "_scenes", 0) > 0:
+            self._released = True
+        else:
+            self._destroy()
+
+
+class GroupScene:
+    """The scene on every device of a group."""
+
+    def __init__(self, group, host_scene_or_desc):
+        self._group = group
+        self._h = C.c_void_p()
+        desc_ptr = host_scene_or_desc.desc_ptr if isinstance(host_scene_or_desc, HostScene) else C.pointer(host_scene_or_desc)
+        _check(load_library().lj_group_scene_upload(group._h, desc_ptr, C.byref(self._h)))
+        group._scenes += 1
+        info = LjSceneInfo()
+        _check(load_library().lj_scene_info(load_library().lj_group_scene_member(self._h, 0), C.byref(info)))
+        self.info = info
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None and not sys.is_finalizing():
+            _lib.lj_group_scene_destroy(self._h)
+            self._h = None
+            self._group._scenes -= 1
+            if self._group._released and self._group._scenes == 0:
+                self._group._destroy()
+
+    def stats(self):
+        st = LjStats()
+        _check(load_library().lj_group_get_stats(self._h, C.byref(st)))
+        return st
+
+
+def render_group(group_scene, **kw):
+    """render() across a device group: tiles sharded t % N, one sum-reduce onto device 0 -> (h, w, 3) float32."""
+    args = make_args(**kw)
+    out = np.empty((group_scene.info.height, group_scene.info.width, 3), np.float32)
+    _check(load_library().lj_group_render(group_scene._h, C.byref(args), out.ctypes.data_as(C.c_void_p)))
+    return out

@@ -219,4 +219,14 @@ SYMBOLS = [
     ("lj_pcg32_queries", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p]),
     ("lj_texture_queries", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     ("lj_frame_queries", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    ("lj_group_create", C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]),
+    ("lj_group_destroy", None, [C.c_void_p]),
+    ("lj_group_size", C.c_int, [C.c_void_p]),
+    ("lj_group_context", C.c_void_p, [C.c_void_p, C.c_int]),
+    ("lj_group_uses_rccl", C.c_int, [C.c_void_p]),
+    ("lj_group_scene_upload", C.c_int, [C.c_void_p, C.POINTER(LjSceneDesc), C.POINTER(C.c_void_p)]),
+    ("lj_group_scene_destroy", None, [C.c_void_p]),
+    ("lj_group_scene_member", C.c_void_p, [C.c_void_p, C.c_int]),
+    ("lj_group_render", C.c_int, [C.c_void_p, C.POINTER(LjRenderArgs), C.c_void_p]),
+    ("lj_group_get_stats", C.c_int, [C.c_void_p, C.POINTER(LjStats)]),
 ]

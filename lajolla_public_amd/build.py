@@ -22,7 +22,7 @@ ORACLE_LIB = os.path.join(ROOT, "oracle", "_build", "liblj_oracle.so")
 TWIN_LIB = os.path.join(ROOT, "tests", "twin", "_build", "libljtwin.so")
 
 HOST_SOURCES = ["host/api_host.cpp", "host/scene_xml.cpp", "host/mesh_io.cpp", "host/image_io.cpp", "host/jpeg_decode.cpp", "host/exr_decode.cpp", "host/flatten.cpp", "host/bvh.cpp"]
-HIP_SOURCES = ["device/kernels.hip", "device/api_device.hip", "device/queries.hip", "device/mega.hip"]
+HIP_SOURCES = ["device/kernels.hip", "device/api_device.hip", "device/queries.hip", "device/mega.hip", "device/group.hip"]
 ARCH = "gfx950"
 
 

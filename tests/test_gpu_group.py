@@ -1,0 +1,56 @@
+"""Device groups (include/lajolla_hip.h): the tile loop sharded over N devices from one process, frames sum-reduced onto device 0.
+On the one-GPU test box the N-device path runs as N logical ranks on device 0 (same sharding, same threads, frames summed by a
+device kernel), and the RCCL binding is exercised with a one-rank communicator (LJ_GROUP_FORCE_RCCL=1: dlopen + ncclCommInitAll +
+ncclReduce inside a group call).  Several distinct devices under RCCL are the driver's 8-GPU run: unmeasured here."""
+import os
+
+import numpy as np
+import pytest
+
+import lajolla_public_amd as lj
+from helpers import scene_path
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,spp", [("cbox", 4), ("sponza", 1)])
+def test_logical_ranks_sum_to_the_single_device_image(name, spp):
+    hs = lj.parse_scene(scene_path(name))
+    one = lj.Scene(lj.Context(0), hs)
+    want = lj.render(one, spp=spp)
+    for n in (1, 2, 5):
+        g = lj.DeviceGroup([0] * n)
+        assert g.size == n and not g.uses_rccl
+        gs = lj.GroupScene(g, hs)
+        got = lj.render_group(gs, spp=spp)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (name, n)
+        st = gs.stats()
+        assert st.samples == hs.width * hs.height * spp
+        again = lj.render_group(gs, spp=spp)   # back to back: the frames of the previous render are cleared, not accumulated
+        assert np.array_equal(again.view(np.uint32), want.view(np.uint32))
+
+
+def test_group_refuses_rank_arguments_and_bad_devices():
+    g = lj.DeviceGroup([0, 0])
+    gs = lj.GroupScene(g, lj.parse_scene(scene_path("cbox")))
+    with pytest.raises(lj.LajollaError) as e:
+        lj.render_group(gs, spp=1, rank=1, world_size=2)
+    assert "shards by itself" in str(e.value)
+    with pytest.raises(lj.LajollaError):
+        lj.DeviceGroup([0, 99])
+    with pytest.raises(lj.LajollaError):
+        lj.DeviceGroup([])
+
+
+def test_rccl_binding_with_a_one_rank_communicator():
+    os.environ["LJ_GROUP_FORCE_RCCL"] = "1"
+    try:
+        g = lj.DeviceGroup([0])
+    finally:
+        os.environ.pop("LJ_GROUP_FORCE_RCCL", None)
+    assert g.uses_rccl
+    hs = lj.parse_scene(scene_path("cbox"))
+    gs = lj.GroupScene(g, hs)
+    got = lj.render_group(gs, spp=2)
+    want = lj.render(lj.Scene(lj.Context(0), hs), spp=2)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
