@@ -18,8 +18,12 @@ CSRC = os.path.join(ROOT, "lajolla_public_amd", "csrc")
 _VARIANT = os.environ.get("LJ_VARIANT", "")
 BUILD = os.path.join(ROOT, "build" + ("_" + _VARIANT if _VARIANT else ""))
 LIB = os.path.join(ROOT, "lajolla_public_amd", "liblajolla_hip" + ("_" + _VARIANT if _VARIANT else "") + ".so")
-ORACLE_LIB = os.path.join(ROOT, "oracle", "_build", "liblj_oracle.so")
-TWIN_LIB = os.path.join(ROOT, "tests", "twin", "_build", "libljtwin.so")
+# LJ_SANITIZE=1 (tools/sanitize_cpu.sh): AddressSanitizer + UndefinedBehaviorSanitizer builds of the two CPU-side test libraries
+# (the GPU pool offers no device sanitizer; the host twin compiles the very device headers, so it is the next best thing)
+_SAN = bool(os.environ.get("LJ_SANITIZE"))
+_SAN_FLAGS = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-g"] if _SAN else []
+ORACLE_LIB = os.path.join(ROOT, "oracle", "_build", "liblj_oracle_asan.so" if _SAN else "liblj_oracle.so")
+TWIN_LIB = os.path.join(ROOT, "tests", "twin", "_build", "libljtwin_asan.so" if _SAN else "libljtwin.so")
 
 HOST_SOURCES = ["host/api_host.cpp", "host/scene_xml.cpp", "host/mesh_io.cpp", "host/image_io.cpp", "host/jpeg_decode.cpp", "host/exr_decode.cpp", "host/flatten.cpp", "host/bvh.cpp"]
 HIP_SOURCES = ["device/kernels.hip", "device/api_device.hip", "device/queries.hip", "device/mega.hip", "device/group.hip"]
@@ -114,7 +118,7 @@ def build_oracle(verbose=True):
     if _stale(ORACLE_LIB, [src, os.path.join(ROOT, "include", "lajolla_hip.h")]):
         if verbose:
             print("[build] compiling the CPU oracle (test infrastructure)", file=sys.stderr)
-        _run(["g++", "-std=c++17", "-O2", "-ffp-contract=off"] + _host_fma_flag() + ["-fPIC", "-shared", "-Wall", "-Wno-unused-function",
+        _run(["g++", "-std=c++17", "-O1" if _SAN else "-O2", "-ffp-contract=off"] + _SAN_FLAGS + _host_fma_flag() + ["-fPIC", "-shared", "-Wall", "-Wno-unused-function",
               "-o", ORACLE_LIB, src, "-lpthread"])
     return ORACLE_LIB
 
@@ -128,7 +132,7 @@ def build_twin(verbose=True):
     if _stale(TWIN_LIB, deps):
         if verbose:
             print("[build] compiling the host twin of the device headers (CPU-side tests only)", file=sys.stderr)
-        _run(["g++", "-std=c++17", "-O2", "-ffp-contract=off"] + _host_fma_flag() + ["-fPIC", "-shared", "-Wall", "-Wno-unused-function",
+        _run(["g++", "-std=c++17", "-O1" if _SAN else "-O2", "-ffp-contract=off"] + _SAN_FLAGS + _host_fma_flag() + ["-fPIC", "-shared", "-Wall", "-Wno-unused-function",
               "-o", TWIN_LIB, src, os.path.join(CSRC, "host/flatten.cpp"), os.path.join(CSRC, "host/bvh.cpp"), "-lpthread"])
     return TWIN_LIB
 
