@@ -54,23 +54,23 @@ def kernel_source_sha():
 
 
 def profiled_counters(kernel):
-    """HBM bytes per launch (and VALU issue share) of `kernel` from this round's committed rocprofv3 PMC passes of the same
-    workload (profiles/<ROUND>_hbm_traffic.json, written by tools/prof_bench.sh: FETCH_SIZE and WRITE_SIZE in separate
-    passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16 B/lane streams, divided by that pass's own launch
-    count).  Returns (None, reason) when the file is missing or was measured on other kernel sources."""
-    path = os.path.join(ROOT, "profiles", f"{ROUND}_hbm_traffic.json")
+    """Hardware counters of `kernel` from this round's committed rocprofv3 PMC passes of the same workload
+    (profiles/<ROUND>_counters.json, written by tools/evidence_r02.sh: FETCH_SIZE, WRITE_SIZE and two SQ sets in separate
+    runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16 B/lane streams; totals over one render's launches).
+    Returns (None, reason) when the file is missing or was measured on other kernel sources: a stale profile is never quoted."""
+    path = os.path.join(ROOT, "profiles", f"{ROUND}_counters.json")
     try:
         t = json.load(open(path))
     except (OSError, ValueError):
-        return None, f"no profiles/{ROUND}_hbm_traffic.json"
+        return None, f"no profiles/{ROUND}_counters.json"
     if t.get("kernel_source_sha") != kernel_source_sha():
-        return None, f"profiles/{ROUND}_hbm_traffic.json was measured on other kernel sources (stale)"
+        return None, f"profiles/{ROUND}_counters.json was measured on other kernel sources (stale)"
     k = t.get("kernels", {}).get(kernel)
-    if not k:
-        return None, f"{kernel} not in profiles/{ROUND}_hbm_traffic.json"
-    out = {"traffic": int((k["fetch_bytes"] + k["write_bytes"]) / max(k["launches"], 1)), "source": t.get("source")}
-    if "valu_issue_frac" in k:
-        out["valu_issue_frac"] = k["valu_issue_frac"]
+    if not k or "fetch_bytes" not in k or "write_bytes" not in k:
+        return None, f"{kernel} not in profiles/{ROUND}_counters.json"
+    out = dict(k)
+    out["traffic"] = int((k["fetch_bytes"] + k["write_bytes"]) / max(k["launches"], 1))
+    out["source"] = t.get("source")
     return out, None
 
 
@@ -239,20 +239,34 @@ def main():
     is_default = os.path.basename(args.scene) == "cbox.xml" and spp == 256 and world == 1
     prof, why_not = profiled_counters(dom) if is_default else (None, "only profiled for the default workload")
     whole_gbs = (si.extend_bytes + si.shade_bytes + si.mega_bytes) / (ms_per_step * 1e-3) / 1e9
-    # `bound`: the shade kernel streams the queue (HBM); the extend kernel is divergent BVH traversal whose queue traffic is a
-    # fraction of its time — it is limited by vector-instruction issue at partial lane occupancy (profiles/<ROUND>_summary.md),
-    # so its HBM fraction is reported for the record, not as the bound it runs against.  k_mega keeps the path state in registers:
-    # its only HBM traffic is the finished radiance, and what bounds it is vector-instruction issue (valu_issue_frac).
-    roofline = {"bound": "hbm" if dom == "k_shade" else "valu", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                "frac": round(achieved / PEAK_HBM_GBS, 5), "frac_of_measured_copy": round(achieved / COPY_HBM_GBS, 5),
-                "traffic": prof["traffic"] if prof else None, "traffic_source": prof["source"] if prof else why_not,
-                "avg_launch_us": round(avg_us, 2), "algorithmic_bytes_per_launch": int(kd["bytes"] / max(kd["launches"], 1)),
-                "all_kernels": {k: {"total_ms": round(v["ms"], 3), "launches": int(v["launches"]),
-                                    "GBps": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 2)} for k, v in kernels.items()},
-                "whole_step_GBps": round(whole_gbs, 2), "whole_step_frac": round(whole_gbs / PEAK_HBM_GBS, 5),
-                "whole_step_frac_of_measured_copy": round(whole_gbs / COPY_HBM_GBS, 5)}
-    if prof and "valu_issue_frac" in prof:
-        roofline["valu_issue_frac"] = prof["valu_issue_frac"]
+    # `bound`: the shade kernel streams the queue (HBM).  The extend kernel is divergent BVH traversal whose queue traffic is a
+    # fraction of its time, and k_mega keeps the path state in registers (its only HBM traffic is the finished radiance): both are
+    # limited by vector-instruction issue, so their roofline is wave-instructions per second against the chip's issue peak
+    # (256 CUs x 4 SIMD-32, one wave64 instruction per 2 cycles, 2.4 GHz: MI355X_MICROARCH.md) — with the instruction count taken
+    # from this round's committed PMC pass of the same workload and the duration measured live here.  Their algorithmic HBM
+    # figure is still reported beside it (hbm_*).
+    PEAK_GWINST = 1024 * 2.4 / 2
+    hbm = {"achieved": round(achieved, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 5),
+           "frac_of_measured_copy": round(achieved / COPY_HBM_GBS, 5)}
+    roofline = {"bound": "hbm", "kernel": dom}
+    roofline.update(hbm)
+    if dom != "k_shade":
+        roofline["bound"] = "valu"
+        if prof and prof.get("valu_wave_insts"):
+            insts_per_launch = prof["valu_wave_insts"] / max(prof["launches"], 1)
+            a = insts_per_launch / (avg_us * 1e-6) / 1e9
+            roofline.update({"achieved": round(a, 1), "peak": PEAK_GWINST, "unit": "G wave-instructions/s", "frac": round(a / PEAK_GWINST, 5),
+                             "valu_active_lane_frac": prof.get("valu_active_lane_frac"), "valu_wave_insts_per_launch": int(insts_per_launch)})
+            roofline.pop("frac_of_measured_copy", None)
+            roofline["hbm_algorithmic"] = hbm
+        else:
+            roofline["note"] = "VALU-bound kernel, but no current PMC profile to take its instruction count from (%s): the figures are its algorithmic HBM rate" % why_not
+    roofline.update({"traffic": prof["traffic"] if prof else None, "traffic_source": prof["source"] if prof else why_not,
+                     "avg_launch_us": round(avg_us, 2), "algorithmic_bytes_per_launch": int(kd["bytes"] / max(kd["launches"], 1)),
+                     "all_kernels": {k: {"total_ms": round(v["ms"], 3), "launches": int(v["launches"]),
+                                         "GBps": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 2)} for k, v in kernels.items()},
+                     "whole_step_GBps": round(whole_gbs, 2), "whole_step_frac": round(whole_gbs / PEAK_HBM_GBS, 5),
+                     "whole_step_frac_of_measured_copy": round(whole_gbs / COPY_HBM_GBS, 5)})
 
     if rank == 0:
         name = os.path.basename(args.scene)
