@@ -1,5 +1,5 @@
 // Host BVH builder: replaces Embree's rtcCommitScene (scene.cpp:20-27, build quality HIGH) with a binned-SAH
-// binary tree collapsed into a BVH4 (largest-area child opened first) whose nodes are emitted breadth-first — a
+// binary tree with spatial splits (SBVH) collapsed into a BVH4 (largest-area child opened first) whose nodes are emitted breadth-first — a
 // prefix of the node array is the top of the tree, which is what the extend kernel stages into LDS.  Each node record
 // carries the boxes of its four children (one 128-byte fetch per step).
 #include "flatten.h"
@@ -7,6 +7,8 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <cstdlib>
+#include <cstdio>
 
 namespace lj {
 
@@ -31,69 +33,171 @@ struct TmpNode {
     int depth = 0;
 };
 
+// One reference to a primitive: its (possibly clipped) padded box.  Object splits move references; a spatial split cuts the ones
+// that straddle its plane in two (Stich et al., "Spatial Splits in Bounding Volume Hierarchies", HPG 2009 — what Embree's
+// RTC_BUILD_QUALITY_HIGH, which the reference asks for at scene.cpp:22, builds).
+struct Ref { Box box; int prim; };
+
 struct Builder {
     const std::vector<BuildPrim> &prims;
-    std::vector<int> order;
-    std::vector<float> centroid;  // 3 per prim
+    std::vector<int> order;       // leaf order: primitive ids, one leaf after the other
     std::vector<TmpNode> tmp;
     int max_leaf, max_depth;
+    bool spatial;                 // spatial splits allowed at all
+    size_t ref_budget;            // total references the tree may hold (duplication cap)
+    size_t refs_total;
+    float root_area;
+    float alpha = 1e-5f, gain = 0.98f;   // overlap threshold (fraction of the root's area) and the factor a spatial split has to beat the object split by
 
-    int build(int first, int count, int depth) {
-        int id = (int)tmp.size();
-        tmp.emplace_back();
-        Box box, cbox;
-        for (int i = 0; i < count; i++) {
-            int p = order[first + i];
-            box.grow(prims[p].lo, prims[p].hi);
-            cbox.grow(&centroid[3 * p], &centroid[3 * p]);
+    static void pad(Box &b) {     // the builder's box padding (flatten.cpp): a box test may accept a box the exact ray misses, never the reverse
+        for (int k = 0; k < 3; k++) {
+            const float l = b.lo[k], h = b.hi[k];
+            const float p = 1e-5f * (std::fabs(l) + std::fabs(h)) + 1e-7f * (h - l) + 1e-30f;
+            b.lo[k] = l - p; b.hi[k] = h + p;
         }
+    }
+    // box of the part of reference r inside the slab [a, b] of `axis`: the triangle clipped (in double), or the box cut for a sphere
+    Box clip(const Ref &r, int axis, float a, float b) const {
+        Box out;
+        const BuildPrim &p = prims[r.prim];
+        if (!p.tri) {
+            out = r.box; out.lo[axis] = std::max(out.lo[axis], a); out.hi[axis] = std::min(out.hi[axis], b);
+            return out;
+        }
+        double poly[2][10][3]; int n = 3, cur = 0;
+        for (int i = 0; i < 3; i++) for (int k = 0; k < 3; k++) poly[0][i][k] = p.v[i][k];
+        for (int side = 0; side < 2 && n > 0; side++) {   // keep x >= a, then x <= b (Sutherland-Hodgman)
+            const double plane = side == 0 ? (double)a : (double)b, sgn = side == 0 ? 1.0 : -1.0;
+            int m = 0;
+            for (int i = 0; i < n; i++) {
+                const double *P = poly[cur][i], *Q = poly[cur][(i + 1) % n];
+                const double dp = sgn * (P[axis] - plane), dq = sgn * (Q[axis] - plane);
+                if (dp >= 0) { for (int k = 0; k < 3; k++) poly[cur ^ 1][m][k] = P[k]; m++; }
+                if ((dp > 0 && dq < 0) || (dp < 0 && dq > 0)) {
+                    const double t = dp / (dp - dq);
+                    for (int k = 0; k < 3; k++) poly[cur ^ 1][m][k] = P[k] + t * (Q[k] - P[k]);
+                    poly[cur ^ 1][m][axis] = plane; m++;
+                }
+            }
+            cur ^= 1; n = m;
+        }
+        if (n == 0) return out;   // (empty)
+        for (int i = 0; i < n; i++) { float q[3] = {(float)poly[cur][i][0], (float)poly[cur][i][1], (float)poly[cur][i][2]}; out.grow(q, q); }
+        // the builder's padding around the clipped part (it covers the float rounding of the clipped vertices too: a child may reach
+        // past the split plane by that hair), never beyond the reference's own box
+        pad(out);
+        for (int k = 0; k < 3; k++) { out.lo[k] = std::max(out.lo[k], r.box.lo[k]); out.hi[k] = std::min(out.hi[k], r.box.hi[k]); }
+        return out;
+    }
+
+    int build(std::vector<Ref> &refs, int depth) {
+        const int id = (int)tmp.size();
+        tmp.emplace_back();
+        const int count = (int)refs.size();
+        Box box, cbox;
+        for (const Ref &r : refs) { box.grow(r.box); float c[3] = {0.5f * (r.box.lo[0] + r.box.hi[0]), 0.5f * (r.box.lo[1] + r.box.hi[1]), 0.5f * (r.box.lo[2] + r.box.hi[2])}; cbox.grow(c, c); }
         tmp[id].box = box; tmp[id].depth = depth;
-        auto make_leaf = [&]() { tmp[id].first = first; tmp[id].count = count; return id; };
+        auto make_leaf = [&]() { tmp[id].first = (int)order.size(); tmp[id].count = count; for (const Ref &r : refs) order.push_back(r.prim); return id; };
         if (count <= 1 || (depth >= max_depth && count <= 8)) return make_leaf();
-        // binned SAH over the three axes
         constexpr int kBins = 16;
+        // ---- object split: binned SAH over the reference centroids, three axes
         float best_cost = std::numeric_limits<float>::infinity(); int best_axis = -1, best_bin = -1;
+        Box best_l, best_r;
         for (int axis = 0; axis < 3; axis++) {
-            float c0 = cbox.lo[axis], c1 = cbox.hi[axis];
+            const float c0 = cbox.lo[axis], c1 = cbox.hi[axis];
             if (!(c1 > c0)) continue;
             Box bins[kBins]; int counts[kBins] = {0};
-            float scale = kBins / (c1 - c0);
-            for (int i = 0; i < count; i++) {
-                int p = order[first + i];
-                int b = std::min(kBins - 1, std::max(0, (int)((centroid[3 * p + axis] - c0) * scale)));
-                bins[b].grow(prims[p].lo, prims[p].hi); counts[b]++;
+            const float scale = kBins / (c1 - c0);
+            for (const Ref &r : refs) {
+                const float c = 0.5f * (r.box.lo[axis] + r.box.hi[axis]);
+                const int b = std::min(kBins - 1, std::max(0, (int)((c - c0) * scale)));
+                bins[b].grow(r.box); counts[b]++;
             }
-            float right_area[kBins]; int right_count[kBins];
+            Box rbox[kBins]; int right_count[kBins];
             Box acc; int n = 0;
-            for (int b = kBins - 1; b > 0; b--) { acc.grow(bins[b]); n += counts[b]; right_area[b] = acc.half_area(); right_count[b] = n; }
+            for (int b = kBins - 1; b > 0; b--) { acc.grow(bins[b]); n += counts[b]; rbox[b] = acc; right_count[b] = n; }
             acc = Box(); n = 0;
             for (int b = 0; b < kBins - 1; b++) {
                 acc.grow(bins[b]); n += counts[b];
                 if (n == 0 || right_count[b + 1] == 0) continue;
-                float cost = acc.half_area() * n + right_area[b + 1] * right_count[b + 1];
-                if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; }
+                const float cost = acc.half_area() * n + rbox[b + 1].half_area() * right_count[b + 1];
+                if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; best_l = acc; best_r = rbox[b + 1]; }
             }
         }
-        const float leaf_cost = box.half_area() * count;
-        int mid;
-        if (best_axis < 0) {
-            if (count <= max_leaf) return make_leaf();
-            mid = first + count / 2;  // all centroids coincide: split the list in half
-        } else {
-            // 1.0 box-test cost vs 1.2 primitive-test cost, both children boxes are tested in the parent
-            const float split_cost = 1.0f * box.half_area() + best_cost * 1.2f;
-            if (count <= max_leaf && leaf_cost * 1.2f <= split_cost) return make_leaf();
-            float c0 = cbox.lo[best_axis], c1 = cbox.hi[best_axis];
-            float scale = kBins / (c1 - c0);
-            auto it = std::partition(order.begin() + first, order.begin() + first + count, [&](int p) {
-                int b = std::min(kBins - 1, std::max(0, (int)((centroid[3 * p + best_axis] - c0) * scale)));
-                return b <= best_bin;
-            });
-            mid = (int)(it - order.begin());
-            if (mid == first || mid == first + count) mid = first + count / 2;
+        // ---- spatial split: binned over the node's extent, references clipped to the bins they span.  Tried only where the object
+        // split leaves its children overlapping by more than 1e-5 of the root's area (the SBVH restriction), and while the budget lasts.
+        float sp_cost = std::numeric_limits<float>::infinity(); int sp_axis = -1; float sp_plane = 0;
+        if (spatial && refs_total < ref_budget && count > max_leaf) {
+            bool try_it = best_axis < 0;
+            if (!try_it) {
+                Box ov; for (int k = 0; k < 3; k++) { ov.lo[k] = std::max(best_l.lo[k], best_r.lo[k]); ov.hi[k] = std::min(best_l.hi[k], best_r.hi[k]); }
+                try_it = ov.half_area() > alpha * root_area;
+            }
+            for (int axis = 0; try_it && axis < 3; axis++) {
+                const float a0 = box.lo[axis], a1 = box.hi[axis];
+                if (!(a1 > a0)) continue;
+                Box bins[kBins]; int entry[kBins] = {0}, exit_[kBins] = {0};
+                const float width = (a1 - a0) / kBins, scale = kBins / (a1 - a0);
+                for (const Ref &r : refs) {
+                    int b0 = std::min(kBins - 1, std::max(0, (int)((r.box.lo[axis] - a0) * scale)));
+                    int b1 = std::min(kBins - 1, std::max(b0, (int)((r.box.hi[axis] - a0) * scale)));
+                    entry[b0]++; exit_[b1]++;
+                    if (b0 == b1) { bins[b0].grow(r.box); continue; }
+                    for (int b = b0; b <= b1; b++) {
+                        const Box c = clip(r, axis, a0 + b * width, b == kBins - 1 ? a1 : a0 + (b + 1) * width);
+                        if (c.lo[0] <= c.hi[0]) bins[b].grow(c);
+                    }
+                }
+                Box rbox[kBins]; int right_count[kBins];
+                Box acc; int n = 0;
+                for (int b = kBins - 1; b > 0; b--) { acc.grow(bins[b]); n += exit_[b]; rbox[b] = acc; right_count[b] = n; }
+                acc = Box(); n = 0;
+                for (int b = 0; b < kBins - 1; b++) {
+                    acc.grow(bins[b]); n += entry[b];
+                    if (n == 0 || right_count[b + 1] == 0 || n == count || right_count[b + 1] == count) continue;   // (a split that only duplicates is no split)
+                    const float cost = acc.half_area() * n + rbox[b + 1].half_area() * right_count[b + 1];
+                    if (cost < sp_cost) { sp_cost = cost; sp_axis = axis; sp_plane = a0 + (b + 1) * width; }
+                }
+            }
         }
-        int l = build(first, mid - first, depth + 1);
-        int r = build(mid, first + count - mid, depth + 1);
+        if (getenv("LJ_DBG_SBVH") && depth < 4) fprintf(stderr, "depth %d count %d obj cost %g (axis %d) spatial cost %g (axis %d) tried %d\n", depth, count, best_cost, best_axis, sp_cost, sp_axis, (int)(spatial && refs_total < ref_budget && count > max_leaf));
+        const float leaf_cost = box.half_area() * count;
+        std::vector<Ref> left, right;
+        if (sp_axis >= 0 && sp_cost < gain * best_cost) {   // the spatial split has to pay for its duplicates
+            for (const Ref &r : refs) {
+                if (r.box.hi[sp_axis] <= sp_plane) left.push_back(r);
+                else if (r.box.lo[sp_axis] >= sp_plane) right.push_back(r);
+                else {
+                    Ref a{clip(r, sp_axis, r.box.lo[sp_axis], sp_plane), r.prim}, b{clip(r, sp_axis, sp_plane, r.box.hi[sp_axis]), r.prim};
+                    const bool va = a.box.lo[0] <= a.box.hi[0], vb = b.box.lo[0] <= b.box.hi[0];
+                    if (va) left.push_back(a);
+                    if (vb) right.push_back(b);
+                    if (!va && !vb) left.push_back(r);
+                }
+            }
+            if (left.empty() || right.empty() || left.size() == refs.size() || right.size() == refs.size()) { left.clear(); right.clear(); }
+            else refs_total += left.size() + right.size() - refs.size();
+        }
+        if (left.empty()) {
+            if (best_axis < 0) {
+                if (count <= max_leaf) return make_leaf();
+                left.assign(refs.begin(), refs.begin() + count / 2); right.assign(refs.begin() + count / 2, refs.end());   // all centroids coincide: halve the list
+            } else {
+                // 1.0 box-test cost vs 1.2 primitive-test cost, both children boxes are tested in the parent
+                const float split_cost = 1.0f * box.half_area() + best_cost * 1.2f;
+                if (count <= max_leaf && leaf_cost * 1.2f <= split_cost) return make_leaf();
+                const float c0 = cbox.lo[best_axis], c1 = cbox.hi[best_axis], scale = kBins / (c1 - c0);
+                for (const Ref &r : refs) {
+                    const float c = 0.5f * (r.box.lo[best_axis] + r.box.hi[best_axis]);
+                    const int b = std::min(kBins - 1, std::max(0, (int)((c - c0) * scale)));
+                    (b <= best_bin ? left : right).push_back(r);
+                }
+                if (left.empty() || right.empty()) { left.assign(refs.begin(), refs.begin() + count / 2); right.assign(refs.begin() + count / 2, refs.end()); }
+            }
+        }
+        std::vector<Ref>().swap(refs);   // (release before recursing)
+        const int l = build(left, depth + 1);
+        const int r = build(right, depth + 1);
         tmp[id].left = l; tmp[id].right = r;
         return id;
     }
@@ -112,11 +216,21 @@ void build_bvh(const std::vector<BuildPrim> &prims, int max_leaf, int max_depth,
         return nd;
     };
     if (n == 0) { nodes.push_back(empty_node()); depth_out = 1; return; }
-    Builder b{prims, {}, {}, {}, max_leaf, max_depth};
-    b.order.resize(n); b.centroid.resize(3 * (size_t)n);
-    for (int i = 0; i < n; i++) { b.order[i] = i; for (int k = 0; k < 3; k++) b.centroid[3 * i + k] = 0.5f * (prims[i].lo[k] + prims[i].hi[k]); }
+    // Spatial splits for scenes beyond the tiny ones (those run the flat leaf scan of mega.hip, which indexes primitives with 16 bits
+    // and wants no duplicates); at most 30 % more references than primitives.  LJ_TUNE_SBVH=0 turns them off.
+    const bool spatial = n > 256 && !(getenv("LJ_TUNE_SBVH") && atoi(getenv("LJ_TUNE_SBVH")) == 0);
+    double budget = 0.3;
+    if (const char *e = getenv("LJ_TUNE_SBVH_BUDGET")) budget = atof(e);
+    Builder b{prims, {}, {}, max_leaf, max_depth, spatial, (size_t)n + (size_t)(budget * n), (size_t)n, 0.0f};
+    std::vector<Ref> refs((size_t)n);
+    Box rootb;
+    for (int i = 0; i < n; i++) { refs[i].prim = i; for (int k = 0; k < 3; k++) { refs[i].box.lo[k] = prims[i].lo[k]; refs[i].box.hi[k] = prims[i].hi[k]; } rootb.grow(refs[i].box); }
+    b.root_area = rootb.half_area();
+    if (const char *e = getenv("LJ_TUNE_SBVH_ALPHA")) b.alpha = (float)atof(e);
+    if (const char *e = getenv("LJ_TUNE_SBVH_GAIN")) b.gain = (float)atof(e);
+    b.order.reserve((size_t)n + n / 3);
     b.tmp.reserve(2 * (size_t)n);
-    const int root = b.build(0, n, 0);
+    const int root = b.build(refs, 0);
     // Leaves hold at most 8 primitives (3-bit count in the child code); beyond the depth cap the builder keeps
     // splitting until that holds, and the caller checks the resulting depth against its traversal stack.
     if ((long long)n * 8 >= (1ll << 30)) throw LjError(LJ_ERR_UNSUPPORTED, "too many primitives for the 30-bit leaf code");

@@ -173,7 +173,7 @@ FlatScene flatten_scene(const LjSceneDesc &d) {
             for (int k = 0; k < 3; k++) ps.n0[k] = (float)sh.position[k];
             ps.n1[0] = (float)sh.radius;
             ljd::DPrim p{}; p.gprim = (int)F.prims.size(); p.kind = 1; p.sphere_slot = slot;
-            BuildPrim bp;
+            BuildPrim bp{};
             for (int k = 0; k < 3; k++) {  // sphere_bounds_func (sphere.inl:1-10): double arithmetic stored into float bounds
                 float l = (float)(sh.position[k] - sh.radius), h = (float)(sh.position[k] + sh.radius);
                 lo[k] = std::min(lo[k], l); hi[k] = std::max(hi[k], h);
@@ -192,7 +192,9 @@ FlatScene flatten_scene(const LjSceneDesc &d) {
             V3 p0 = v3(P + 3 * i0), p1 = v3(P + 3 * i1), p2 = v3(P + 3 * i2);
             ljd::DPrim p{}; p.gprim = (int)F.prims.size(); p.kind = 0; p.sphere_slot = 0;
             st3(p.v0, p0); st3(p.v1, p1); st3(p.v2, p2);  // triangle_mesh.inl:11-14
-            BuildPrim bp;
+            BuildPrim bp{};
+            bp.tri = 1;
+            for (int k = 0; k < 3; k++) { bp.v[0][k] = p.v0[k]; bp.v[1][k] = p.v1[k]; bp.v[2][k] = p.v2[k]; }
             for (int k = 0; k < 3; k++) {
                 float l = std::min(p.v0[k], std::min(p.v1[k], p.v2[k])), h = std::max(p.v0[k], std::max(p.v1[k], p.v2[k]));
                 lo[k] = std::min(lo[k], l); hi[k] = std::max(hi[k], h);
@@ -239,7 +241,7 @@ FlatScene flatten_scene(const LjSceneDesc &d) {
     int max_leaf = 4;
     if (const char *e = getenv("LJ_TUNE_MAX_LEAF")) max_leaf = std::min(8, std::max(1, atoi(e)));
     build_bvh(bprims, max_leaf, 38, F.nodes, order, F.bvh_depth);
-    F.leaf_prims.resize(gprims.size());
+    F.leaf_prims.resize(order.size());   // (>= gprims.size(): a primitive cut by a spatial split sits in a leaf on either side)
     for (size_t i = 0; i < order.size(); i++) F.leaf_prims[i] = gprims[order[i]];
     // ---- flat leaf table of a tiny scene (device/dscan.h): the leaves of the tree with their (padded) boxes, one 32-byte
     // record each, for the scan-based traversal that tests every leaf box of the scene for every ray (no stack, no node

@@ -41,9 +41,13 @@ struct FlatScene {
 // Throws LjError(LJ_ERR_UNSUPPORTED) for variant alternatives the device path does not implement.
 FlatScene flatten_scene(const LjSceneDesc &d);
 
-// bvh.cpp — binned-SAH tree over padded float boxes, collapsed to a BVH4; fills nodes (breadth-first) and leaf order.
+// bvh.cpp — binned-SAH tree with spatial splits (SBVH) over padded float boxes, collapsed to a BVH4; fills nodes (breadth-first)
+// and leaf order.
 // depth_out = number of inner (wide) levels; a traversal needs at most 3 * depth_out stack entries.
-struct BuildPrim { float lo[3], hi[3]; };
+// `tri`: the primitive is the triangle v[0..2] (float vertices as the device tests them) — what a spatial split clips; else
+// only its box is known (spheres).  leaf_order lists the primitives of the leaves one leaf after the other; with spatial
+// splits a primitive that straddles a split plane is referenced by a leaf on either side, so the list may be longer than `prims`.
+struct BuildPrim { float lo[3], hi[3]; float v[3][3]; int tri; };
 void build_bvh(const std::vector<BuildPrim> &prims, int max_leaf, int max_depth,
                std::vector<ljd::DNode4> &nodes, std::vector<int> &leaf_order, int &depth_out);
 

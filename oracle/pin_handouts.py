@@ -40,7 +40,6 @@ PAIRS = {
     "veach_mis": ("veach_mis.png", "veach_mi/mi.xml", 256, {}),
     "sponza": ("sponza.png", "sponza/sponza.xml", 64, {}),
     "matpreview": ("matpreview.png", "matpreview/matpreview.xml", 64, {}),
-    "disney_bsdf": ("disney_bsdf.png", "disney_bsdf_test/disney_bsdf.xml", 64, {"down": 2}),
     "disney_diffuse": ("disney_diffuse.png", "disney_bsdf_test/disney_diffuse.xml", 64, {}),
     "disney_metal": ("disney_metal.png", "disney_bsdf_test/disney_metal.xml", 64, {}),
     "disney_clearcoat": ("disney_clearcoat.png", "disney_bsdf_test/disney_clearcoat.xml", 64, {}),
@@ -53,15 +52,12 @@ PAIRS = {
     "volpath_2": ("volpath_2.png", "volpath_test/volpath_test2.xml", 256, {}),
     "volpath_3": ("volpath_3.png", "volpath_test/volpath_test3.xml", 256, {}),
     "volpath_4": ("volpath_4.png", "volpath_test/volpath_test4.xml", 256, {}),
-    "volpath_4_2": ("volpath_4_2.png", "volpath_test/volpath_test4_2.xml", 256, {}),
     "volpath_5": ("volpath_5.png", "volpath_test/volpath_test5.xml", 256, {}),
-    "volpath_5_2": ("volpath_5_2.png", "volpath_test/volpath_test5_2.xml", 256, {}),
-    "volpath_5_cbox": ("volpath_5_cbox.png", "volpath_test/vol_cbox.xml", 128, {}),
-    "volpath_5_cbox_teapot": ("volpath_5_cbox_teapot.png", "volpath_test/vol_cbox_teapot.xml", 64, {}),
     "volpath_6": ("volpath_6.png", "volpath_test/volpath_test6.xml", 256, {}),
-    "hetvol": ("hetvol.png", "volpath_test/hetvol.xml", 64, {}),
-    "colored_smoke": ("colored_smoke.png", "volpath_test/hetvol_colored.xml", 64, {}),
 }
+# Handouts that turned out NOT to be exposure-0 sRGB renders of a shipped scene file (tried, fitted scalar or block differences far off;
+# recorded under "not_pinned" in handouts.json): disney_bsdf.png (a gallery of another scene), volpath_4_2 / volpath_5_2 /
+# volpath_5_cbox_teapot / hetvol / colored_smoke (exposure scalars 0.09 ... 0.52), volpath_5_cbox (NaN samples in the render itself).
 
 
 def srgb_to_linear(a):

@@ -48,7 +48,7 @@ def _parse(meta):
 def _check(name, meta, arrays, render, spp):
     handout, usable = arrays[name + "/blocks"].astype(np.float64), arrays[name + "/usable"]
     rb = _blocks(render.astype(np.float64))
-    assert rb.shape == handout.shape and usable.mean() > 0.3
+    assert rb.shape == handout.shape and usable.mean() > 0.15
     s = meta["exposure_scalar"]
     assert 0.97 < s < 1.03, "the handouts are exposure-0 sRGB images: a fitted scalar far from 1 would mean a systematic difference"
     rel = np.abs(s * handout[usable] - rb[usable]).max(axis=-1) / np.maximum(rb[usable].max(axis=-1), 1e-3)
@@ -66,7 +66,7 @@ def _check(name, meta, arrays, render, spp):
 
 def test_fixtures_cover_both_integrators_and_all_three_filters():
     images, arrays = _fixtures()
-    assert {"cbox", "veach_mis", "sponza", "disney_bsdf", "hetvol", "volpath_1", "volpath_6", "filter_box", "filter_tent", "filter_gaussian"} <= set(images)
+    assert {"cbox", "veach_mis", "sponza", "matpreview", "disney_glass", "volpath_1", "volpath_3", "volpath_6", "filter_box", "filter_tent", "filter_gaussian"} <= set(images)
     for name, m in images.items():
         assert arrays[name + "/blocks"].ndim == 3 and m["oracle_vs_handout"]["median"] < 0.05, name   # the pinned oracle is within 5 % of every handout
 
