@@ -47,7 +47,7 @@ struct Builder {
     size_t ref_budget;            // total references the tree may hold (duplication cap)
     size_t refs_total;
     float root_area;
-    float alpha = 1e-5f, gain = 0.98f;   // overlap threshold (fraction of the root's area) and the factor a spatial split has to beat the object split by
+    float alpha = 1e-5f, gain = 1.0f;   // overlap threshold (fraction of the root's area) and the factor a spatial split has to beat the object split by
 
     static void pad(Box &b) {     // the builder's box padding (flatten.cpp): a box test may accept a box the exact ray misses, never the reverse
         for (int k = 0; k < 3; k++) {
@@ -160,7 +160,6 @@ struct Builder {
                 }
             }
         }
-        if (getenv("LJ_DBG_SBVH") && depth < 4) fprintf(stderr, "depth %d count %d obj cost %g (axis %d) spatial cost %g (axis %d) tried %d\n", depth, count, best_cost, best_axis, sp_cost, sp_axis, (int)(spatial && refs_total < ref_budget && count > max_leaf));
         const float leaf_cost = box.half_area() * count;
         std::vector<Ref> left, right;
         if (sp_axis >= 0 && sp_cost < gain * best_cost) {   // the spatial split has to pay for its duplicates
@@ -217,9 +216,10 @@ void build_bvh(const std::vector<BuildPrim> &prims, int max_leaf, int max_depth,
     };
     if (n == 0) { nodes.push_back(empty_node()); depth_out = 1; return; }
     // Spatial splits for scenes beyond the tiny ones (those run the flat leaf scan of mega.hip, which indexes primitives with 16 bits
-    // and wants no duplicates); at most 30 % more references than primitives.  LJ_TUNE_SBVH=0 turns them off.
+    // and wants no duplicates); at most twice as many references as primitives (sponza ends at 1.36x: -16 % node steps and -30 %
+    // primitive tests per extension ray against the object-split tree).  LJ_TUNE_SBVH=0 turns them off.
     const bool spatial = n > 256 && !(getenv("LJ_TUNE_SBVH") && atoi(getenv("LJ_TUNE_SBVH")) == 0);
-    double budget = 0.3;
+    double budget = 1.0;
     if (const char *e = getenv("LJ_TUNE_SBVH_BUDGET")) budget = atof(e);
     Builder b{prims, {}, {}, max_leaf, max_depth, spatial, (size_t)n + (size_t)(budget * n), (size_t)n, 0.0f};
     std::vector<Ref> refs((size_t)n);
