@@ -225,7 +225,9 @@ def main():
     lj.render_device(scene, frame.data_ptr(), stream=stream.cuda_stream, spp=spp, rank=rank, world_size=world, pool_paths=args.pool, flags=1)
     torch.cuda.synchronize(dev)
     si = scene.stats()
-    if si.mega_launches > 0:   # a tiny scene: one fused persistent launch per pass (mega.hip), no path queue
+    if scene.info.integrator == 6:   # volumetric path tracer: one launch per pass, a lane walks a whole path (k_volpath); timed as a whole
+        kernels = {"k_volpath": {"ms": si.render_ms, "launches": max(int(si.wavefront_steps), 1), "bytes": si.samples * 12}}
+    elif si.mega_launches > 0:   # a tiny scene: one fused persistent launch per pass (mega.hip), no path queue
         kernels = {"k_mega": {"ms": si.mega_ms, "launches": si.mega_launches, "bytes": si.mega_bytes}}
     else:
         kernels = {

@@ -120,7 +120,7 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
             ljd::launch_volpath(ds, pass, (uint32_t)total, (unsigned long long *)ctx->chunk_counter.p, sc->ecfg,
                                 ensure_spill(ctx, sc->ecfg.spill_levels, (uint32_t)grid), grid, stream);
             HIP_CHECK(hipGetLastError());
-            st.samples += total;
+            st.samples += total; st.wavefront_steps++;
             if (rgb_dev) ljd::launch_resolve(pass, (uint32_t)np, rgb_dev, stream);
             if (samples_host) {
                 HIP_CHECK(hipMemcpyAsync(samples_host + p0 * (uint64_t)plan.spp * 3, ctx->sample_rgb.p, total * 12, hipMemcpyDeviceToHost, stream));
