@@ -111,6 +111,17 @@ def write_image(path, rgb):
     _check(load_library().lj_image_write(os.fsencode(path), a.shape[1], a.shape[0], a.ctypes.data_as(C.c_void_p)))
 
 
+def read_image(path, channels=3):
+    """imread3 / imread1 (image.cpp:28-133): (h, w, channels) float32, y = 0 at the top."""
+    lib = load_library()
+    w, h, data = C.c_int32(), C.c_int32(), C.POINTER(C.c_float)()
+    _check(lib.lj_image_read(os.fsencode(path), int(channels), C.byref(w), C.byref(h), C.byref(data)))
+    try:
+        return np.ctypeslib.as_array(data, shape=(h.value, w.value, int(channels))).copy()
+    finally:
+        lib.lj_image_free(data)
+
+
 class Context:
     """One HIP device + stream + workspace."""
 

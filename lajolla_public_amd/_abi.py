@@ -208,6 +208,8 @@ SYMBOLS = [
     ("lj_get_stats", C.c_int, [C.c_void_p, C.POINTER(LjStats)]),
     ("lj_scene_info", C.c_int, [C.c_void_p, C.POINTER(LjSceneInfo)]),
     ("lj_image_write", C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.c_void_p]),
+    ("lj_image_read", C.c_int, [C.c_char_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.POINTER(C.c_float))]),
+    ("lj_image_free", None, [C.POINTER(C.c_float)]),
     ("lj_shade_variant_count", C.c_int, []),
     ("lj_scene_shade_variant", C.c_int, [C.c_void_p]),
     ("lj_bsdf_queries", C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),

@@ -2,6 +2,8 @@
 // (Device entry points live in ../device/api_device.hip.)
 #include "host_scene.h"
 #include "api_common.h"
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 namespace lj {
@@ -39,5 +41,19 @@ int lj_image_write(const char *filename, int32_t width, int32_t height, const fl
         lj::write_image(filename, width, height, rgb);
     });
 }
+
+int lj_image_read(const char *filename, int32_t channels, int32_t *width, int32_t *height, float **data) {
+    return lj::guard([&]() {
+        if (!filename || !width || !height || !data || (channels != 1 && channels != 3)) throw lj::LjError(LJ_ERR_INVALID_ARG, "lj_image_read: null argument or channels not 1 / 3");
+        *data = nullptr;
+        lj::HostImage img = lj::read_image(filename, channels);
+        float *out = (float *)malloc(std::max<size_t>(img.data.size(), 1) * sizeof(float));
+        if (!out) throw std::bad_alloc();
+        memcpy(out, img.data.data(), img.data.size() * sizeof(float));
+        *width = img.width; *height = img.height; *data = out;
+    });
+}
+
+void lj_image_free(float *data) { free(data); }
 
 } // extern "C"

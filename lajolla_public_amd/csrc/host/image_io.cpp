@@ -5,6 +5,7 @@
 //   .pfm          portable float map (colour "PF" / grey "Pf"), bottom-up, endianness by the sign of the scale
 //   .jpg / .jpeg  baseline JPEG (jpeg_decode.cpp), then the LDR -> linear conversion stb's stbi_loadf applies:
 //                 (float) pow(v / 255.0f, 2.2f)  (stb_image.h:1553,1849) — what the reference's ImageTextures hold.
+//   .png / .hdr   PNG (all colour types and bit depths, Adam7) and Radiance RGBE (png_decode.cpp), with stb's conventions
 //   .exr          single-part scan-line OpenEXR, HALF / FLOAT / UINT channels, NONE / ZIPS / ZIP / PIZ (exr_decode.cpp);
 //                 three channels = R, G, B; one channel = their mean (image.cpp:70-72)
 // Other formats fail loudly.
@@ -20,6 +21,8 @@ namespace lj {
 
 std::vector<uint8_t> decode_jpeg_rgb8(const std::vector<uint8_t> &file, int &width, int &height, const std::string &name);
 HostImage decode_exr_rgb(const std::vector<uint8_t> &file, const std::string &name);
+HostImage read_png(const std::vector<uint8_t> &file, const std::string &name, int channels);   // png_decode.cpp
+HostImage read_hdr(const std::vector<uint8_t> &file, const std::string &name, int channels);
 
 namespace {
 
@@ -98,7 +101,14 @@ HostImage read_image(const std::string &filename, int channels) {
         }
         return img;
     }
-    throw LjError(LJ_ERR_UNSUPPORTED, "image format '" + ext + "' is not decoded by this build yet (SURVEY §8f-2): " + filename);
+    if (ext == ".png" || ext == ".hdr") {
+        std::ifstream f(filename, std::ios::binary);
+        if (!f) throw LjError(LJ_ERR_IO, "cannot open image: " + filename);
+        std::vector<uint8_t> bytes((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+        return ext == ".png" ? read_png(bytes, filename, channels) : read_hdr(bytes, filename, channels);
+    }
+    // (the reference also passes .tga / .bmp / .psd / .gif / .pic to stb_image, image.cpp:31-38; no shipped scene uses them)
+    throw LjError(LJ_ERR_UNSUPPORTED, "image format '" + ext + "' is not decoded by this build (JPEG, PNG, Radiance HDR, OpenEXR and PFM are): " + filename);
 }
 
 // ------------------------------------------------------------------ imwrite (image.cpp:135-173)

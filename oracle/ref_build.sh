@@ -6,6 +6,7 @@
 #                             parse_obj load_serialized parse_scene scene medium phase_function volume
 #                             intersection + 3rdparty/pugixml.cpp + 3rdparty/miniz.c
 #   oracle/_ref/gen_golden    oracle/gen_golden.cpp linked against it
+#   oracle/_ref/decode_with_reference   oracle/decode_with_reference.cpp: the reference's imread3 / imread1 on tests/assets/images/*
 #
 # The full reference is UNBUILDABLE here: embree/lib-linux/libembree3.so.3 is listed in .MISSING_LARGE_BLOBS.
 # The 20 rtc* symbols stay unresolved in libljref.so (lazy binding); nothing we call reaches them, and we do
@@ -33,9 +34,12 @@ for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
 g++ -shared -o "$OUT/libljref.so" "$OUT"/obj/*.o -Wl,-z,lazy -lpthread
 g++ $CXXFLAGS -o "$OUT/gen_golden" "$HERE/gen_golden.cpp" -L"$OUT" -lljref \
     -Wl,--allow-shlib-undefined -Wl,-z,lazy -Wl,-rpath,"$OUT" -lpthread
-echo "ref_build: built $OUT/libljref.so and $OUT/gen_golden"
+g++ $CXXFLAGS -o "$OUT/decode_with_reference" "$HERE/decode_with_reference.cpp" -L"$OUT" -lljref \
+    -Wl,--allow-shlib-undefined -Wl,-z,lazy -Wl,-rpath,"$OUT" -lpthread
+echo "ref_build: built $OUT/libljref.so, $OUT/gen_golden and $OUT/decode_with_reference"
 if [ "${1:-}" = "--golden" ]; then
   mkdir -p "$HERE/../tests/golden"
   "$OUT/gen_golden" "$REF" "$HERE/../tests/golden"
+  "$OUT/decode_with_reference" "$HERE/../tests/golden/image_decode.json" "$HERE"/../tests/assets/images/*
   echo "ref_build: wrote $(ls "$HERE/../tests/golden" | wc -l) fixtures to tests/golden/"
 fi

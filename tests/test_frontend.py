@@ -267,3 +267,38 @@ def test_media_match_reference_parser(name):
             assert close(vox.sum(axis=0), gv["data_sum"], rel=1e-12)
             st = max(1, n // 17)
             assert np.array_equal(vox[::st], np.array(gv["samples"]))
+
+
+def _fnv1a64(a):
+    h = 1469598103934665603
+    for b in np.ascontiguousarray(a, "<f4").tobytes():
+        h = ((h ^ b) * 1099511628211) & 0xffffffffffffffff
+    return "%016x" % h
+
+
+def test_png_and_hdr_decoders_match_the_reference_loaders():
+    """imread3 / imread1 hand .png and .hdr files to stb_image (image.cpp:28-133).  tests/assets/images/ holds small files of every PNG
+    colour type / bit depth / filter type, Adam7, palettes with tRNS, and Radiance HDR in its three encodings (written by
+    oracle/make_image_assets.py); tests/golden/image_decode.json is what the reference's own loaders return for them
+    (oracle/decode_with_reference.cpp).  Our decoders (png_decode.cpp) must return the same floats, bit for bit."""
+    g = golden("image_decode")["files"]
+    assert len(g) >= 23 and {"gray1.png", "rgb16_interlaced.png", "pal4.png", "graya16.png", "rle.hdr", "flat_wide.hdr", "narrow.hdr"} <= set(g)
+    for name, e in sorted(g.items()):
+        for ch, key in ((3, "imread3"), (1, "imread1")):
+            img = lj.read_image(os.path.join(ROOT, "tests", "assets", "images", name), ch)
+            assert img.shape == (e[key]["height"], e[key]["width"], ch), (name, key)
+            n = len(e[key]["first_texels"])
+            assert np.array_equal(img.reshape(-1)[:n], np.array(e[key]["first_texels"], np.float32)), (name, key)
+            assert _fnv1a64(img.reshape(-1)) == e[key]["fnv1a64"], (name, key)
+
+
+def test_unsupported_and_broken_images_fail_loudly(tmp_path):
+    for name, payload in (("x.tga", b"\0" * 64), ("x.png", b"\x89PNG\r\n\x1a\n" + b"\0" * 40), ("x.hdr", b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 2 +X 9\n\2\2\0")):
+        p = tmp_path / name
+        p.write_bytes(payload)
+        with pytest.raises(lj.LajollaError) as e:
+            lj.read_image(str(p), 3)
+        assert e.value.code in (_abi.LJ_ERR_UNSUPPORTED, _abi.LJ_ERR_PARSE)
+    with pytest.raises(lj.LajollaError) as e:
+        lj.read_image(str(tmp_path / "missing.png"), 3)
+    assert e.value.code == _abi.LJ_ERR_IO
