@@ -206,9 +206,10 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
     DevBuf xstats_buf;
     if (getenv("LJ_EXTEND_STATS")) { xstats_buf.alloc(64); HIP_CHECK(hipMemsetAsync(xstats_buf.p, 0, 64, stream)); xstats = (unsigned long long *)xstats_buf.p; }
     uint32_t n_lanes = (timing || xstats || pool < (1u << 20)) ? 1u : (pool < (1u << 22) ? 2u : 4u);
-    // the Disney / all-features shade kernels (164 VGPRs, three waves per SIMD) leave an extend kernel few registers to run beside them:
-    // two lanes still overlap a little (disney_bsdf 64 spp: 29.5 ms with one lane, 27.5 with two, 29.7 with four)
-    if (sc->scfg.variant >= 3) n_lanes = std::min<uint32_t>(n_lanes, 2u);   // (FeatDisney, FeatAll)
+    // the Disney / all-features shade kernels (164 VGPRs, three waves per SIMD) leave an extend kernel no registers to run beside
+    // them: lanes would only time-slice the GPU (disney_bsdf 256 spp: 104 ms with one lane, 116 with two; a 64-spp render, which fits
+    // the pool at once, is the other way round by 7 %)
+    if (sc->scfg.variant >= 3) n_lanes = 1;   // (FeatDisney, FeatAll)
     if (const char *e = getenv("LJ_TUNE_LANES")) n_lanes = (uint32_t)std::min((int)kMaxLanes, std::max(1, atoi(e)));
     uint32_t n_blocks = std::min<uint32_t>(kMaxBlocks, std::max<uint32_t>(n_lanes, std::min<uint32_t>((uint32_t)ctx->n_cus * blocks_per_cu, pool / 256)));
     n_blocks = (n_blocks / n_lanes) * n_lanes;
