@@ -30,6 +30,10 @@ LJ_HD float recip_fast(float s) {
     return 1.0f / s;
 #endif
 }
+// a / b correctly rounded whatever division mode the translation unit is compiled in (the device code is built with hipcc's fast
+// fp32 division and square root, build.py): the quotient of two floats computed in double and rounded once more is the IEEE float
+// quotient (53 >= 2 * 24 + 2 bits).  Used where a value must match the CPU oracle bit for bit: the hit distance and barycentrics.
+LJ_HD float div_ieee(float a, float b) { return (float)((double)a / (double)b); }
 LJ_HD f3 operator/(f3 a, float s) { float inv = recip_fast(s); return mk3(a.x * inv, a.y * inv, a.z * inv); }
 LJ_HD float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 LJ_HD f3 cross(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }

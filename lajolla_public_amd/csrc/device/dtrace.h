@@ -44,14 +44,14 @@ LJ_HD bool tri_test_raw(const RayF &r, float tfar, const float *p0, const float 
     float nx = LJ_TRI_CROSS(e1y, e0z, e1z, e0y), ny = LJ_TRI_CROSS(e1z, e0x, e1x, e0z), nz = LJ_TRI_CROSS(e1x, e0y, e1y, e0x);
     float den = LJ_TRI_DOT(nx, ny, nz, r.dx, r.dy, r.dz);
     float T = LJ_TRI_DOT(nx, ny, nz, ax, ay, az);
-    float t = T / den;
+    float t = div_ieee(T, den);
     t_out = t; U_out = U; V_out = V; S_out = S;
     return (S != 0.0f) & (den != 0.0f) & (t > r.tnear) & (t <= tfar);
 }
 LJ_HD bool tri_test(const RayF &r, float tfar, const float *p0, const float *p1, const float *p2, float &t_out, float &u_out, float &v_out) {
     float U, V, S;
     if (!tri_test_raw(r, tfar, p0, p1, p2, t_out, U, V, S)) return false;
-    const float rS = 1.0f / S;
+    const float rS = div_ieee(1.0f, S);
     u_out = U * rS; v_out = V * rS;
     return true;
 }

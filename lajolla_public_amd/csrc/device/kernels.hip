@@ -133,7 +133,7 @@ __device__ __forceinline__ int trav_pop(const TreeView &tv, LaneTrav &L) {
 
 // the one barycentric division of a closest-hit query (dtrace.h tri_test: u = U * (1 / S))
 __device__ __forceinline__ void trav_finish(LaneTrav &L) {
-    const float rS = 1.0f / L.best_S;
+    const float rS = div_ieee(1.0f, L.best_S);
     L.best.u = L.best.u * rS; L.best.v = L.best.v * rS;
 }
 
@@ -518,7 +518,7 @@ __global__ void __launch_bounds__(kBlock) k_resolve(DPass pass, uint32_t n_pixel
     for (int o = 32; o > 0; o >>= 1) { r += __shfl_xor(r, o, 64); g += __shfl_xor(g, o, 64); b += __shfl_xor(b, o, 64); }
     if (lane == 0) {
         const uint32_t pixel = pass.pixel_list[wave];
-        const float inv = 1.0f / (float)pass.spp;
+        const float inv = div_ieee(1.0f, (float)pass.spp);
         rgb[3ull * pixel] = r * inv; rgb[3ull * pixel + 1] = g * inv; rgb[3ull * pixel + 2] = b * inv;
     }
 }

@@ -156,7 +156,7 @@ __device__ __forceinline__ void scan_trace(const ScanCtx &sx, bool has_e, bool h
             const float v0[3] = {p0.x, p0.y, p0.z}, v1[3] = {p1.x, p1.y, p1.z}, v2[3] = {p2.x, p2.y, p2.z};
             float t, U, V, Ssum;
             (void)tri_test_raw(ray, INFINITY, v0, v1, v2, t, U, V, Ssum);
-            const float rS = 1.0f / Ssum;   // (trav_finish of k_extend)
+            const float rS = div_ieee(1.0f, Ssum);   // (trav_finish of k_extend)
             hu = U * rS; hv = V * rS;
         }
     }
