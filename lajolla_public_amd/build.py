@@ -89,11 +89,11 @@ def build_product(verbose=True):
         objs.append(o)
         # -fno-slp-vectorize: packed-fp32 pairs (v_pk_add/mul/fma_f32) cost more in register shuffling than they save
         # in these kernels (measured: -6 % cbox, -14 % veach_mi, -1..4 % elsewhere; 12 fewer VGPRs in the extend kernel)
-        # -fno-hip-fp32-correctly-rounded-divide-sqrt: the shading code's ~90 float divisions and 25 square roots become v_rcp / v_sqrt
-        # sequences (2.5 ulp) instead of the IEEE expansions (-2 % time on every scene; the parity bars are 2e-5 and looser).  The values
-        # that must match the CPU oracle bit for bit — hit distance, barycentrics — go through div_ieee (dmath.h), which is exact in any mode.
+        # (not built with -fno-hip-fp32-correctly-rounded-divide-sqrt: the 2.5-ulp divisions are 2 % faster on every scene, but the
+        # volumetric tracker's long chains of accept / reject decisions then leave the oracle's path in most samples of a dense medium —
+        # vol_cbox per-sample parity went from a median 2e-7 to 0.15 — and sponza's per-sample median crossed its 1e-4 bar: measured, dropped)
         cmd = [_hipcc(), "-std=c++17", "-O3", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
-               "-fno-gpu-rdc", "-fno-slp-vectorize", "-fno-hip-fp32-correctly-rounded-divide-sqrt"] + os.environ.get("LJ_EXTRA_HIPCC_FLAGS", "").split() + ["-c", s, "-o", o]
+               "-fno-gpu-rdc", "-fno-slp-vectorize"] + os.environ.get("LJ_EXTRA_HIPCC_FLAGS", "").split() + ["-c", s, "-o", o]
         if _stale(o, [s] + headers) or not _same_cmd(o, cmd):
             jobs.append(cmd)
     if jobs:

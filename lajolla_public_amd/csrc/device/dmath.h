@@ -30,8 +30,8 @@ LJ_HD float recip_fast(float s) {
     return 1.0f / s;
 #endif
 }
-// a / b correctly rounded whatever division mode the translation unit is compiled in (the device code is built with hipcc's fast
-// fp32 division and square root, build.py): the quotient of two floats computed in double and rounded once more is the IEEE float
+// a / b correctly rounded whatever division mode the translation unit is compiled in (hipcc can build fp32 division as a 2.5-ulp
+// sequence, see build.py): the quotient of two floats computed in double and rounded once more is the IEEE float
 // quotient (53 >= 2 * 24 + 2 bits).  Used where a value must match the CPU oracle bit for bit: the hit distance and barycentrics.
 LJ_HD float div_ieee(float a, float b) { return (float)((double)a / (double)b); }
 LJ_HD f3 operator/(f3 a, float s) { float inv = recip_fast(s); return mk3(a.x * inv, a.y * inv, a.z * inv); }
