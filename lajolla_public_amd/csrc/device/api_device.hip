@@ -36,7 +36,8 @@ int *ensure_spill(lj_context *ctx, int levels, uint32_t grid) {
 
 struct RenderPlan {
     int spp; uint32_t pool; uint64_t seed;
-    std::vector<uint32_t> pixels;  // rendered pixels in tile order
+    std::shared_ptr<const std::vector<uint32_t>> pixels;  // rendered pixels in tile order (cached per scene: same share -> same list)
+    uint64_t pixels_key = 0;                               // identifies the list on the device (lj_context::pixel_list_key)
     int max_depth;
 };
 
@@ -57,20 +58,39 @@ RenderPlan make_plan(const lj_scene *sc, const LjRenderArgs *a) {
     int cx0 = crop ? a->crop_x0 : 0, cy0 = crop ? a->crop_y0 : 0, cx1 = crop ? a->crop_x1 : w, cy1 = crop ? a->crop_y1 : h;
     if (cx0 < 0 || cy0 < 0 || cx1 > w || cy1 > h) throw LjError(LJ_ERR_INVALID_ARG, "crop window outside the film");
     const int tile = 16, ntx = (w + tile - 1) / tile, nty = (h + tile - 1) / tile;  // render.cpp:75-77
+    // the pixel list depends on the share only (rank, world, crop): a render loop asks for the same one every frame
+    const uint64_t key_parts[9] = {(uint64_t)rank, (uint64_t)world, (uint64_t)crop, (uint64_t)cx0, (uint64_t)cy0, (uint64_t)cx1, (uint64_t)cy1, (uint64_t)w, (uint64_t)h};
+    uint64_t key = 1469598103934665603ull;
+    for (uint64_t v : key_parts) { key ^= v + 0x9e3779b97f4a7c15ull; key *= 1099511628211ull; }
+    key ^= (uint64_t)(uintptr_t)sc; key |= 1ull;
+    lj_scene *msc = const_cast<lj_scene *>(sc);
+    if (msc->plan_pixels && msc->plan_pixels_key == key) { p.pixels = msc->plan_pixels; p.pixels_key = key; return p; }
+    auto pixels = std::make_shared<std::vector<uint32_t>>();
     if (crop) {  // crop windows are enumerated row-major (lj_render_samples layout)
         for (int y = cy0; y < cy1; y++) for (int x = cx0; x < cx1; x++) {
             int t = (y / tile) * ntx + (x / tile);
-            if (t % world == rank) p.pixels.push_back((uint32_t)(y * w + x));
+            if (t % world == rank) pixels->push_back((uint32_t)(y * w + x));
         }
     } else {
         for (int t = 0; t < ntx * nty; t++) {
             if (t % world != rank) continue;
             int tx = t % ntx, ty = t / ntx;
             int x0 = tx * tile, x1 = std::min(x0 + tile, w), y0 = ty * tile, y1 = std::min(y0 + tile, h);
-            for (int y = y0; y < y1; y++) for (int x = x0; x < x1; x++) p.pixels.push_back((uint32_t)(y * w + x));
+            for (int y = y0; y < y1; y++) for (int x = x0; x < x1; x++) pixels->push_back((uint32_t)(y * w + x));
         }
     }
+    p.pixels = pixels; p.pixels_key = key;
+    msc->plan_pixels = pixels; msc->plan_pixels_key = key;
     return p;
+}
+
+// the plan's pixel list on the device; the copy is skipped when the context still holds this very list
+void upload_pixel_list(lj_context *ctx, const RenderPlan &plan, hipStream_t stream) {
+    const size_t n = plan.pixels->size();
+    if (ctx->pixel_list.bytes < n * 4) { ctx->pixel_list.alloc(n * 4); ctx->pixel_list_key = 0; }
+    if (ctx->pixel_list_key == plan.pixels_key && plan.pixels_key != 0) return;
+    HIP_CHECK(hipMemcpyAsync(ctx->pixel_list.p, plan.pixels->data(), n * 4, hipMemcpyHostToDevice, stream));
+    ctx->pixel_list_key = plan.pixels_key;
 }
 
 // Renders plan.pixels; if rgb_dev != null writes radiance/spp there (other pixels untouched), if samples_host != null
@@ -80,13 +100,12 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
     set_device(ctx);
     ljd::DScene ds = sc->dscene;
     ds.max_depth = plan.max_depth;
-    const uint64_t n_pix = plan.pixels.size();
+    const uint64_t n_pix = plan.pixels->size();
     LjStats &st = sc->stats; st = LjStats{};
     if (n_pix == 0) return;
     if (sc->flat.integrator < LJ_INTEGRATOR_PATH) {   // auxiliary buffers: one primary ray per pixel, no queue
         if (samples_host) throw LjError(LJ_ERR_UNSUPPORTED, "the auxiliary integrators have one deterministic value per pixel, no per-sample values");
-        if (ctx->pixel_list.bytes < n_pix * 4) ctx->pixel_list.alloc(n_pix * 4);
-        HIP_CHECK(hipMemcpyAsync(ctx->pixel_list.p, plan.pixels.data(), n_pix * 4, hipMemcpyHostToDevice, stream));
+        upload_pixel_list(ctx, plan, stream);
         HIP_CHECK(hipEventRecord(ctx->ev_begin, stream));
         const int grid = (int)std::min<uint64_t>((n_pix + 255) / 256, (uint64_t)ctx->n_cus * 4);
         ljd::launch_aux(sc->dscene, (const uint32_t *)ctx->pixel_list.p, (uint32_t)n_pix, sc->flat.integrator, rgb_dev, sc->ecfg,
@@ -105,9 +124,8 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
     if (sc->flat.integrator == LJ_INTEGRATOR_VOLPATH) {   // volumetric path tracer: one lane per sample, whole path (dvol.h)
         const uint64_t pass_samples_max = pix_per_pass * (uint64_t)plan.spp;
         if (ctx->sample_rgb.bytes < pass_samples_max * 12) ctx->sample_rgb.alloc(pass_samples_max * 12);
-        if (ctx->pixel_list.bytes < n_pix * 4) ctx->pixel_list.alloc(n_pix * 4);
         if (!ctx->chunk_counter.p) ctx->chunk_counter.alloc(128 * kMaxLanes);
-        HIP_CHECK(hipMemcpyAsync(ctx->pixel_list.p, plan.pixels.data(), n_pix * 4, hipMemcpyHostToDevice, stream));
+        upload_pixel_list(ctx, plan, stream);
         HIP_CHECK(hipMemsetAsync(ctx->chunk_counter.p, 0, 8, stream));
         HIP_CHECK(hipEventRecord(ctx->ev_begin, stream));
         for (uint64_t p0 = 0; p0 < n_pix; p0 += pix_per_pass) {
@@ -141,9 +159,8 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
     if (mega_lds > 0 && !mega_off) {
         const uint64_t pass_samples_max = pix_per_pass * (uint64_t)plan.spp;
         if (ctx->sample_rgb.bytes < pass_samples_max * 12) ctx->sample_rgb.alloc(pass_samples_max * 12);
-        if (ctx->pixel_list.bytes < n_pix * 4) ctx->pixel_list.alloc(n_pix * 4);
         if (!ctx->mega_state.p) ctx->mega_state.alloc(64);
-        HIP_CHECK(hipMemcpyAsync(ctx->pixel_list.p, plan.pixels.data(), n_pix * 4, hipMemcpyHostToDevice, stream));
+        upload_pixel_list(ctx, plan, stream);
         HIP_CHECK(hipEventRecord(ctx->ev_begin, stream));
         int per_cu = ljd::mega_blocks_per_cu(sc->scfg);
         if (const char *e = getenv("LJ_TUNE_MEGA_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(e));
@@ -251,8 +268,7 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
         L.spill_tail = L.spill;
     }
     if (ctx->sample_rgb.bytes < pass_samples_max * 12) ctx->sample_rgb.alloc(pass_samples_max * 12);
-    if (ctx->pixel_list.bytes < n_pix * 4) ctx->pixel_list.alloc(n_pix * 4);
-    HIP_CHECK(hipMemcpyAsync(ctx->pixel_list.p, plan.pixels.data(), n_pix * 4, hipMemcpyHostToDevice, stream));
+    upload_pixel_list(ctx, plan, stream);
     HIP_CHECK(hipEventRecord(ctx->ev_begin, stream));
     double extend_ms = 0, shade_ms = 0;
     for (uint64_t p0 = 0; p0 < n_pix; p0 += pix_per_pass) {

@@ -67,6 +67,7 @@ struct lj_context {
     DevBuf chunk_counter, chunk_list;  // the extend kernel's work counters and the two lists of live queue chunks
     DevBuf spill;  // overflow levels of the traversal stacks: spill_levels x (grid * 256) ints
     DevBuf blocks, sample_rgb, pixel_list, frame;
+    uint64_t pixel_list_key = 0;   // which pixel list `pixel_list` holds (RenderPlan::pixels_key), 0: none
     DevBuf mega_state;   // k_mega: [0] the grid-wide camera-sample counter (uint32), [8..] five 64-bit statistics
     ljd::DBlockState *blocks_host = nullptr;  // pinned, kMaxBlocks entries
     hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_k0 = nullptr, ev_k1 = nullptr;
@@ -81,6 +82,7 @@ struct lj_scene {
     ljd::ExtendConfig ecfg{};
     ljd::ShadeConfig scfg{};
     uint32_t feat_kinds = 0; bool feat_textured = false, feat_envmap = false, feat_sphere_lights = false;   // what the scene holds (picks scfg.variant)
+    std::shared_ptr<const std::vector<uint32_t>> plan_pixels; uint64_t plan_pixels_key = 0;   // the last render plan's pixel list (make_plan)
     std::vector<int64_t> shape_first_gprim;   // global primitive id of each shape's first primitive (shape order, then triangle order)
     LjStats stats{};
 };
