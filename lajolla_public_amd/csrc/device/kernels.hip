@@ -591,7 +591,10 @@ struct DevTracer {
     }
 };
 
-__global__ void __launch_bounds__(kBlock) k_volpath(DScene sc, DPass pass, uint32_t n_samples, unsigned long long *bounce_counter, int stack, int lds_nodes, int lds_prims, int *spill) {
+#ifndef LJ_VOLPATH_OCC
+#define LJ_VOLPATH_OCC 3   // 252 VGPRs unconstrained (two waves per SIMD); built for three (168, some spilled): -11 ... -22 % on the scenes with scattering (volpath_test4 / 6, hetvol, vol_cbox_teapot), +6 % on volpath_test2; four waves: slower again
+#endif
+__global__ void __launch_bounds__(kBlock, LJ_VOLPATH_OCC) k_volpath(DScene sc, DPass pass, uint32_t n_samples, unsigned long long *bounce_counter, int stack, int lds_nodes, int lds_prims, int *spill) {
     const TreeView tv = stage_tree(sc, stack, lds_nodes, lds_prims, spill, gridDim.x * kBlock, blockIdx.x * kBlock + threadIdx.x);
     DevTracer tr{tv};
     uint32_t bounces = 0;
