@@ -240,7 +240,10 @@ __device__ __forceinline__ void trav_leaf_step(const TreeView &tv, LaneTrav &L, 
 #define LJ_EXT_RESIDENT_OCC 4
 #endif
 template <bool STATS, bool RESIDENT, bool SPHERES>
-__global__ void __launch_bounds__(kBlock, (RESIDENT && !SPHERES && !STATS) ? LJ_EXT_RESIDENT_OCC : 4) k_extend(DScene sc, DQueue q, const DBlockState *blocks, uint32_t seg, uint32_t *work, const uint32_t *chunk_list, uint32_t parity, int stack, int lds_nodes, int lds_prims, int *spill, uint32_t refill_min, uint32_t min_descending, unsigned long long *stats) {
+#ifndef LJ_EXT_GENERAL_OCC
+#define LJ_EXT_GENERAL_OCC 4
+#endif
+__global__ void __launch_bounds__(kBlock, (RESIDENT && !SPHERES && !STATS) ? LJ_EXT_RESIDENT_OCC : (STATS ? 4 : LJ_EXT_GENERAL_OCC)) k_extend(DScene sc, DQueue q, const DBlockState *blocks, uint32_t seg, uint32_t *work, const uint32_t *chunk_list, uint32_t parity, int stack, int lds_nodes, int lds_prims, int *spill, uint32_t refill_min, uint32_t min_descending, unsigned long long *stats) {
     unsigned long long st_outer = 0, st_busy = 0, st_nodes = 0, st_node_lanes = 0, st_leaf = 0, st_leaf_lanes = 0, st_refill = 0, st_rays = 0;
     const TreeView tv = stage_tree(sc, stack, lds_nodes, lds_prims, spill, gridDim.x * kBlock, blockIdx.x * kBlock + threadIdx.x);
     // Persistent waves: the shade launch before this one listed the chunks (kChunk queue slots inside one of its
