@@ -41,32 +41,48 @@ struct ScanCtx {
 
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
-// Bit k of the result: the ray segment [tnear, tfar] overlaps leaf box k.  Same slab arithmetic as the BVH node step
+// Leaf-box scan: bit k of a ray's mask = its segment [tnear, tfar] overlaps leaf box k.  Same slab arithmetic as the BVH node step
 // (t = plane * (1/d) - o * (1/d), v_rcp reciprocals, exit widened by 4 ulp; the boxes carry the builder's 1e-5 padding), with
 // min / max instead of sign-selected planes because the planes are scalars here.  A direction component closer to zero than
 // 1e-18 is moved there: the slab then spans |t| < 1e18 * (distance to the plane) instead of producing inf - inf.  It can only
 // mis-decide a slab whose plane lies within float rounding of the ray's origin, and the padding keeps every primitive of the box
 // 100 times further inside than that.
-__device__ __forceinline__ uint32_t scan_leaf_boxes(const ScanCtx &sx, f3 org, f3 dir, float tnear, float tfar) {
+struct ScanRay { float ix, iy, iz, ox, oy, oz; };
+__device__ __forceinline__ ScanRay scan_ray(f3 org, f3 dir) {
     const float tiny = 1e-18f;
     const float dx = fabsf(dir.x) < tiny ? copysignf(tiny, dir.x) : dir.x, dy = fabsf(dir.y) < tiny ? copysignf(tiny, dir.y) : dir.y,
                 dz = fabsf(dir.z) < tiny ? copysignf(tiny, dir.z) : dir.z;
-    const float ix = __builtin_amdgcn_rcpf(dx), iy = __builtin_amdgcn_rcpf(dy), iz = __builtin_amdgcn_rcpf(dz);
-    const float ox = org.x * ix, oy = org.y * iy, oz = org.z * iz;
-    uint32_t m = 0;
+    ScanRay r;
+    r.ix = __builtin_amdgcn_rcpf(dx); r.iy = __builtin_amdgcn_rcpf(dy); r.iz = __builtin_amdgcn_rcpf(dz);
+    r.ox = org.x * r.ix; r.oy = org.y * r.iy; r.oz = org.z * r.iz;
+    return r;
+}
+// one box against one ray; FAR: the segment has a far end (shadow rays; extension rays run to infinity)
+template <bool FAR>
+__device__ __forceinline__ bool scan_box(const LJ_CONST float *b, const ScanRay &r, float tnear, float tfar) {
+    const float ax = __builtin_fmaf(b[0], r.ix, -r.ox), bx = __builtin_fmaf(b[3], r.ix, -r.ox);
+    const float ay = __builtin_fmaf(b[1], r.iy, -r.oy), by = __builtin_fmaf(b[4], r.iy, -r.oy);
+    const float az = __builtin_fmaf(b[2], r.iz, -r.oz), bz = __builtin_fmaf(b[5], r.iz, -r.oz);
+    const float te = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tnear));
+    float tx = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    if (FAR) tx = fminf(tx, tfar);
+    return te <= tx * 1.0000005f;
+}
+// Both rays of a path against every leaf box in ONE pass over the table: the boxes are fetched (scalar loads) and unpacked once, and the
+// two independent slab chains interleave.  `any_s` (wave-uniform): some lane has a shadow ray — else that half is skipped.
+__device__ __forceinline__ void scan_leaf_boxes2(const ScanCtx &sx, f3 org, f3 dir_e, float tnear_e, f3 dir_s, float tnear_s, float tfar_s, bool any_e, bool any_s,
+                                                 uint32_t &me, uint32_t &ms) {
+    const ScanRay re = scan_ray(org, dir_e), rs = scan_ray(org, dir_s);
+    me = 0u; ms = 0u;
     for (int g = 0; g < sx.n_groups; g++) {
         const LJ_CONST float *b = sx.boxes + g * 32;
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-            const float ax = __builtin_fmaf(b[c * 8 + 0], ix, -ox), bx = __builtin_fmaf(b[c * 8 + 3], ix, -ox);
-            const float ay = __builtin_fmaf(b[c * 8 + 1], iy, -oy), by = __builtin_fmaf(b[c * 8 + 4], iy, -oy);
-            const float az = __builtin_fmaf(b[c * 8 + 2], iz, -oz), bz = __builtin_fmaf(b[c * 8 + 5], iz, -oz);
-            const float te = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tnear));
-            const float tx = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tfar));
-            m |= (te <= tx * 1.0000005f) ? (1u << (g * 4 + c)) : 0u;
+            const uint32_t bit = 1u << (g * 4 + c);
+            if (any_e) me |= scan_box<false>(b + c * 8, re, tnear_e, INFINITY) ? bit : 0u;
+            if (any_s) ms |= scan_box<true>(b + c * 8, rs, tnear_s, tfar_s) ? bit : 0u;
         }
     }
-    return m;
 }
 
 // Closest hit of every lane's extension ray (has_e) and occlusion of its shadow ray (has_s), wave-synchronous: all 64 lanes
@@ -79,8 +95,8 @@ __device__ __forceinline__ void scan_trace(const ScanCtx &sx, bool has_e, bool h
 #pragma clang fp contract(off)
     const uint32_t lane = lane_id();
     uint32_t me = 0, ms = 0;
-    if (__ballot(has_e) != 0ull) { me = scan_leaf_boxes(sx, org, dir_e, tnear_e, INFINITY); me = has_e ? me : 0u; }
-    if (__ballot(has_s) != 0ull) { ms = scan_leaf_boxes(sx, org, dir_s, tnear_s, tfar_s); ms = has_s ? ms : 0u; }
+    scan_leaf_boxes2(sx, org, dir_e, tnear_e, dir_s, tnear_s, tfar_s, __ballot(has_e) != 0ull, __ballot(has_s) != 0ull, me, ms);
+    me = has_e ? me : 0u; ms = has_s ? ms : 0u;
     v4f r0, r1, r2;
     r0.x = org.x; r0.y = org.y; r0.z = org.z; r0.w = tfar_s;
     r1.x = dir_e.x; r1.y = dir_e.y; r1.z = dir_e.z; r1.w = tnear_e;
