@@ -72,6 +72,8 @@ def _same_cmd(target, cmd):
 
 
 def build_product(verbose=True):
+    if os.environ.get("LJ_NO_REBUILD") and os.path.exists(LIB):   # developer A/B runs of a prebuilt LJ_VARIANT library on the GPU box
+        return LIB
     os.makedirs(BUILD, exist_ok=True)
     headers = _headers()
     jobs = []

@@ -107,7 +107,8 @@ LJ_HD void filter_sample(int kind, float param, float r0, float r1, float &ox, f
         oy = r1 < 0.5f ? h * (sqrtf(2 * r1) - 1) : h * (1 - sqrtf(1 - 2 * (r1 - 0.5f)));
     } else {
         float r = param * sqrtf(-2.0f * logf(fmaxf(r0, 1e-8f)));
-        ox = r * cosf(kTwoPi * r1); oy = r * sinf(kTwoPi * r1);
+        float sn, cs; sincos_2pi(r1, sn, cs);
+        ox = r * cs; oy = r * sn;
     }
 }
 LJ_HD f3 xform_point16(const float *m, f3 p) {
@@ -351,8 +352,9 @@ LJ_HD f3 light_emission(const DScene &sc, const DLight &L, f3 view_dir, f3 light
 
 // ------------------------------------------------------------------ BSDFs (materials/*.inl, microfacet.h)
 LJ_HD f3 sample_cos_hemisphere(float r0, float r1) {  // material.cpp:4-11
-    float phi = kTwoPi * r0, tmp = sqrtf(clampf(1.0f - r1, 0.0f, 1.0f));
-    return mk3(cosf(phi) * tmp, sinf(phi) * tmp, sqrtf(clampf(r1, 0.0f, 1.0f)));
+    float sn, cs, tmp = sqrtf(clampf(1.0f - r1, 0.0f, 1.0f));
+    sincos_2pi(r0, sn, cs);
+    return mk3(cs * tmp, sn * tmp, sqrtf(clampf(r1, 0.0f, 1.0f)));
 }
 LJ_HD float fresnel_dielectric(float n_dot_i, float eta) {  // microfacet.h:34-56
     float n_dot_t_sq = 1.0f - (1.0f - n_dot_i * n_dot_i) / (eta * eta);
@@ -380,8 +382,9 @@ LJ_HD f3 sample_visible_normals(f3 local_dir_in, float alpha, float r0, float r1
     bool flipped = local_dir_in.z < 0.0f;
     if (flipped) local_dir_in = -local_dir_in;
     f3 hemi = normalize(mk3(alpha * local_dir_in.x, alpha * local_dir_in.y, local_dir_in.z));
-    float r = sqrtf(r0), phi = kTwoPi * r1;
-    float t1 = r * cosf(phi), t2 = r * sinf(phi);
+    float r = sqrtf(r0), sn, cs;
+    sincos_2pi(r1, sn, cs);
+    float t1 = r * cs, t2 = r * sn;
     float s = (1.0f + hemi.z) * 0.5f;
     t2 = (1.0f - s) * sqrtf(1.0f - t1 * t1) + s * t2;
     f3 disk = mk3(t1, t2, sqrtf(fmaxf(0.0f, 1.0f - t1 * t1 - t2 * t2)));
@@ -411,8 +414,9 @@ LJ_HD f3 sample_visible_normals_aniso(f3 local_dir_in, float ax, float ay, float
     bool flipped = local_dir_in.z < 0.0f;
     if (flipped) local_dir_in = -local_dir_in;
     f3 hemi = normalize(mk3(ax * local_dir_in.x, ay * local_dir_in.y, local_dir_in.z));
-    float r = sqrtf(r0), phi = kTwoPi * r1;
-    float t1 = r * cosf(phi), t2 = r * sinf(phi);
+    float r = sqrtf(r0), sn, cs;
+    sincos_2pi(r1, sn, cs);
+    float t1 = r * cs, t2 = r * sn;
     float s = (1.0f + hemi.z) * 0.5f;
     t2 = (1.0f - s) * sqrtf(1.0f - t1 * t1) + s * t2;
     f3 disk = mk3(t1, t2, sqrtf(fmaxf(0.0f, 1.0f - t1 * t1 - t2 * t2)));
@@ -477,8 +481,9 @@ LJ_HD f3 sample_clearcoat_half(float clearcoat_gloss, float r0, float r1) {  // 
     float a = (1.0f - clearcoat_gloss) * 0.1f + clearcoat_gloss * 0.001f, a2 = a * a;
     float cos_e = sqrtf((1.0f - powf(a2, 1.0f - r0)) / (1.0f - a2));
     float sin_e = sqrtf(fmaxf(0.0f, 1.0f - cos_e * cos_e));  // sin(acos(c))
-    float az = kTwoPi * r1;
-    return normalize(mk3(sin_e * cosf(az), sin_e * sinf(az), cos_e));
+    float sn, cs;
+    sincos_2pi(r1, sn, cs);
+    return normalize(mk3(sin_e * cs, sin_e * sn, cos_e));
 }
 
 struct BsdfSample { f3 dir_out; float eta, roughness; bool valid; };
