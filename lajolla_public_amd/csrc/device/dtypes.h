@@ -136,6 +136,7 @@ struct DScene {
     const float *volume_data;
     const int32_t *shape_media;      // per shape: interior, exterior medium id (-1: none)
     int32_t cam_medium, max_null_collisions;
+    int32_t has_heterogeneous_medium;   // some medium is a grid volume (picks the k_volpath instantiation)
     // tiny scenes only (dscan.h): the flat leaf table; n_scan_leaves is a multiple of 4, 0 when the scene has none
     const DScanLeaf *scan_leaves; int32_t n_scan_leaves;
 };
