@@ -594,12 +594,7 @@ struct DevTracer {
     }
 };
 
-// 252 VGPRs unconstrained (two waves per SIMD).  Built for three (168, some spilled) the scenes with homogeneous media run 7-20 % faster at
-// their shipped sample counts (volpath_test4 / 5 / 6, vol_cbox_teapot; volpath_test2 +4 %), but a heterogeneous medium — whose tracker
-// keeps the grid-lookup state live through long null-collision loops — 30 % slower (hetvol 64 spp: 183 -> 238 ms): so two instantiations,
-// picked by whether the scene holds a heterogeneous medium.  Four waves: slower everywhere.
-template <int OCC>
-__global__ void __launch_bounds__(kBlock, OCC) k_volpath(DScene sc, DPass pass, uint32_t n_samples, unsigned long long *bounce_counter, int stack, int lds_nodes, int lds_prims, int *spill) {
+__device__ __forceinline__ void volpath_body(const DScene &sc, const DPass &pass, uint32_t n_samples, unsigned long long *bounce_counter, int stack, int lds_nodes, int lds_prims, int *spill) {
     const TreeView tv = stage_tree(sc, stack, lds_nodes, lds_prims, spill, gridDim.x * kBlock, blockIdx.x * kBlock + threadIdx.x);
     DevTracer tr{tv};
     uint32_t bounces = 0;
@@ -614,6 +609,16 @@ __global__ void __launch_bounds__(kBlock, OCC) k_volpath(DScene sc, DPass pass, 
     }
     const uint32_t wb = wave_sum(bounces);
     if ((threadIdx.x & 63) == 0 && wb) atomicAdd(bounce_counter, (unsigned long long)wb);
+}
+// Two builds of the same body.  Unconstrained it takes 252 VGPRs (two waves per SIMD); built for three waves (168, some spilled) the
+// scenes with homogeneous media run 7-20 % faster at their shipped sample counts (volpath_test4 / 5 / 6, vol_cbox_teapot;
+// volpath_test2 +4 %), but a heterogeneous medium — whose tracker keeps the grid-lookup state live through long null-collision loops —
+// 30 % slower (hetvol 64 spp: 183 -> 238 ms).  The launcher picks by whether the scene holds a heterogeneous medium.
+__global__ void __launch_bounds__(kBlock) k_volpath(DScene sc, DPass pass, uint32_t n_samples, unsigned long long *bounce_counter, int stack, int lds_nodes, int lds_prims, int *spill) {
+    volpath_body(sc, pass, n_samples, bounce_counter, stack, lds_nodes, lds_prims, spill);
+}
+__global__ void __launch_bounds__(kBlock, 3) k_volpath3(DScene sc, DPass pass, uint32_t n_samples, unsigned long long *bounce_counter, int stack, int lds_nodes, int lds_prims, int *spill) {
+    volpath_body(sc, pass, n_samples, bounce_counter, stack, lds_nodes, lds_prims, spill);
 }
 
 // ---------------------------------------------------------------- launchers (called from api_device.hip)
@@ -732,8 +737,8 @@ void launch_volpath(const DScene &sc, const DPass &pass, uint32_t n_samples, uns
     bool hetero = false;
     if (const char *e = getenv("LJ_TUNE_VOLPATH_OCC")) hetero = atoi(e) == 2;
     else hetero = sc.has_heterogeneous_medium != 0;
-    if (hetero) hipLaunchKernelGGL(k_volpath<2>, dim3(grid), dim3(kBlock), cfg.smem, s, sc, pass, n_samples, bounce_counter, cfg.stack, cfg.lds_nodes, cfg.lds_prims, spill);
-    else hipLaunchKernelGGL(k_volpath<3>, dim3(grid), dim3(kBlock), cfg.smem, s, sc, pass, n_samples, bounce_counter, cfg.stack, cfg.lds_nodes, cfg.lds_prims, spill);
+    if (hetero) hipLaunchKernelGGL(k_volpath, dim3(grid), dim3(kBlock), cfg.smem, s, sc, pass, n_samples, bounce_counter, cfg.stack, cfg.lds_nodes, cfg.lds_prims, spill);
+    else hipLaunchKernelGGL(k_volpath3, dim3(grid), dim3(kBlock), cfg.smem, s, sc, pass, n_samples, bounce_counter, cfg.stack, cfg.lds_nodes, cfg.lds_prims, spill);
 }
 void launch_trace_rays(const DScene &sc, const void *rays, long long n, void *hits, unsigned char *occ, const ExtendConfig &cfg, int *spill, int grid, hipStream_t s) {
     hipLaunchKernelGGL(k_trace_rays, dim3(grid), dim3(kBlock), cfg.smem, s, sc, (const RayIO *)rays, n, (HitIO *)hits, occ, cfg.stack, cfg.lds_nodes, cfg.lds_prims, spill);
