@@ -263,8 +263,8 @@ LJ_HD LightSample sample_point_on_light(const DScene &sc, const DLight &L, f3 re
             if (dist_sq < r * r) {
                 const double z = 1.0 - 2.0 * (double)u0;
                 const double r_ = sqrt(fmax(0.0, 1.0 - z * z));
-                const double phi = 2.0 * 3.14159265358979323846 * (double)u1;
-                nx = r_ * cos(phi); ny = r_ * sin(phi); nz = z;
+                float sn, cs; sincos_2pi(u1, sn, cs);   // (the azimuth does not need double: see below)
+                nx = r_ * (double)cs; ny = r_ * (double)sn; nz = z;
             } else {
                 const double dc = sqrt(dist_sq);
                 const double dx = vx / dc, dy = vy / dc, dz = vz / dc;   // dir_to_center
@@ -280,11 +280,14 @@ LJ_HD LightSample sample_point_on_light(const DScene &sc, const DLight &L, f3 re
                 const double cos_max = sqrt(fmax(0.0, 1.0 - sin_max_sq));
                 const double cos_el = (1.0 - (double)u0) + (double)u0 * cos_max;
                 const double sin_el = sqrt(fmax(0.0, 1.0 - cos_el * cos_el));
-                const double azimuth = (double)u1 * 2.0 * 3.14159265358979323846;
+                // What needs double here is the point's distance from the centre (the elevation chain below cancels for a small or
+                // distant light); the azimuth only moves the point ALONG the sphere, so its sin / cos come from the float samplers'
+                // one-instruction sincos (a double sin + cos pair is ~200 instructions of every path-step of a scene lit by a sphere).
+                float sn, cs; sincos_2pi(u1, sn, cs);
                 const double ds = dc * cos_el - sqrt(fmax(0.0, r * r - dc * dc * sin_el * sin_el));
                 const double cos_alpha = (dc * dc + r * r - ds * ds) / (2.0 * dc * r);
                 const double sin_alpha = sqrt(fmax(0.0, 1.0 - cos_alpha * cos_alpha));
-                const double lx = sin_alpha * cos(azimuth), ly = sin_alpha * sin(azimuth), lz = cos_alpha;
+                const double lx = sin_alpha * (double)cs, ly = sin_alpha * (double)sn, lz = cos_alpha;
                 nx = -(ax * lx + bx * ly + dx * lz); ny = -(ay * lx + by * ly + dy * lz); nz = -(az * lx + bz * ly + dz * lz);
             }
             ls.dpos[0] = cx + r * nx; ls.dpos[1] = cy + r * ny; ls.dpos[2] = cz + r * nz;
