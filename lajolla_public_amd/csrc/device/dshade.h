@@ -47,10 +47,15 @@ inline bool variant_covers(int v, uint32_t kinds, bool textured, bool envmap, bo
     return ok;
 }
 
+struct alignas(16) Texel4 { float r, g, b, pad; };
 LJ_HD f3 texel(const DScene &sc, const DImage &img, int level, int x, int y) {
     const DMipLevel lv = img.lv[level];
-    const float *p = sc.texels + lv.offset + ((int64_t)y * lv.w + x) * img.channels;
-    return img.channels >= 3 ? mk3(p[0], p[1], p[2]) : mk3(p[0], p[0], p[0]);
+    if (img.channels >= 3) {   // RGB0 quads, 16-byte aligned (flatten.cpp build_mips): one 16-byte load
+        const Texel4 t = *reinterpret_cast<const Texel4 *>(sc.texels + lv.offset + ((int64_t)y * lv.w + x) * 4);
+        return mk3(t.r, t.g, t.b);
+    }
+    const float v = sc.texels[lv.offset + ((int64_t)y * lv.w + x)];
+    return mk3(v, v, v);
 }
 // Texture coordinates are carried in double: tiled uvs reach tens of units and a 1000-texel image needs ~1e-8 relative
 // precision in the fractional part for the bilinear weights to agree with the reference's double arithmetic; MI355X

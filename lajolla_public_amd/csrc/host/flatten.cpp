@@ -50,8 +50,12 @@ ljd::DImage build_mips(const LjImage &img, std::vector<float> &texels, std::vect
     int w = img.width, h = img.height;
     out.levels = num_levels; out.channels = ch;
     for (int l = 0; l < num_levels; l++) {
+        // colour texels are stored as 16-byte RGB0 quads (one dwordx4 gather per texel instead of three dword loads: a trilinear lookup is
+        // eight texels), grey ones as single floats; every level starts on a 16-byte boundary
+        while (texels.size() % 4) texels.push_back(0.0f);
         out.lv[l].w = w; out.lv[l].h = h; out.lv[l].offset = (int64_t)texels.size();
-        for (double v : cur) texels.push_back((float)v);
+        if (ch == 3) { for (size_t i = 0; i + 2 < cur.size(); i += 3) { texels.push_back((float)cur[i]); texels.push_back((float)cur[i + 1]); texels.push_back((float)cur[i + 2]); texels.push_back(0.0f); } }
+        else for (double v : cur) texels.push_back((float)v);
         if (l == num_levels - 1) break;
         int nw = std::max(w / 2, 1), nh = std::max(h / 2, 1);
         std::vector<double> next((size_t)nw * nh * ch);
