@@ -225,12 +225,120 @@ __device__ __forceinline__ void trav_leaf_step(const TreeView &tv, LaneTrav &L, 
             double td;
             if (sphere_test(L.ray, tv.spheres[__float_as_int(p2.w)], td)) {
                 const float tf = (float)td;
-                if (ANY_HIT) { L.best.gprim = gprim; stop = true; }
-                else if (tf < L.best.t || (tf == L.best.t && (L.best.gprim < 0 || gprim < L.best.gprim))) { L.best.t = tf; L.best.u = 0.0f; L.best.v = 0.0f; L.best_S = 1.0f; L.best.gprim = gprim; }
+                // (selects here too: hipcc 7.2 mis-structurises the branch form `else if (a || (b && (c || d))) { five assignments }` —
+                // lanes that take the tie arm kept their old u, v)
+                const bool take = ANY_HIT | (tf < L.best.t) | ((tf == L.best.t) & ((L.best.gprim < 0) | (gprim < L.best.gprim)));
+                L.best.t = take ? tf : L.best.t; L.best.u = take ? 0.0f : L.best.u; L.best.v = take ? 0.0f : L.best.v;
+                L.best_S = take ? 1.0f : L.best_S; L.best.gprim = take ? gprim : L.best.gprim;
+                stop = ANY_HIT;
             }
         }
     }
     L.cur = stop ? kDone : trav_pop<RESIDENT>(tv, L);
+}
+
+// ---- the leaf phase of k_extend, pooled.  In the while-while loop the lanes that sit on a leaf hold 1 ... 8 primitives each and the
+// others none: tested lane by lane, a primitive round runs at ~30 % lane occupancy (sponza 27 %, disney_bsdf 35 %).  Here the wave lists
+// its (ray, primitive) pairs in LDS and tests them 64 at a time on whichever lane is free; the ray of a pair comes from its owner's
+// registers (ds_bpermute), results are merged per owner by one 64-bit LDS minimum on (t, global primitive id) — the same order the
+// lane-by-lane test applies, so the hit record is the same, bit for bit — and the winner leaves its unnormalised barycentrics beside it.
+#ifndef LJ_EXT_POOL
+#define LJ_EXT_POOL 1
+#endif
+constexpr uint32_t kPoolCap = 256;                                      // pairs listed at a time (a wave holds at most 64 x 8)
+constexpr uint32_t kWavePoolBytes = 64 * 8 + 64 * 16 + kPoolCap * 2;    // keys | winners (U, V, S, t) | items
+struct LeafPool { LJ_LDS unsigned long long *keys; LJ_LDS v4f *win; LJ_LDS uint16_t *items; };
+
+__device__ __forceinline__ LeafPool leaf_pool_at(uint32_t at) {
+    LJ_LDS char *w = (LJ_LDS char *)lj_smem + at + (threadIdx.x >> 6) * kWavePoolBytes;
+    LeafPool lp;
+    lp.keys = (LJ_LDS unsigned long long *)w; lp.win = (LJ_LDS v4f *)(w + 64 * 8); lp.items = (LJ_LDS uint16_t *)(w + 64 * 8 + 64 * 16);
+    lp.keys[threadIdx.x & 63u] = ~0ull;
+    return lp;
+}
+__device__ __forceinline__ float lane_read(int src4, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src4, __float_as_int(v))); }
+
+// Called by the whole wave (the bpermutes need every owner lane active).  `at_leaf`: this lane's L.cur is a leaf.  Returns the number of
+// 64-pair rounds it ran (for the statistics); `n_pairs` the pairs.
+template <bool RESIDENT, bool SPHERES>
+__device__ __forceinline__ uint32_t trav_leaf_pool(const TreeView &tv, const LeafPool &lp, LaneTrav &L, const bool at_leaf, const bool any_hit, uint32_t &n_pairs) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const int code = ~L.cur;
+    const int first = code >> 3, count = at_leaf ? (code & 7) + 1 : 0;
+    uint32_t rounds = 0;
+    n_pairs = 0;
+    for (int j = 0;;) {
+        // ---- list the pairs: pass j takes the j-th primitive of every leaf (neighbouring pairs then belong to different rays)
+        uint32_t n_items = 0;
+        for (;;) {
+            const bool has = count > j;
+            const unsigned long long b = __ballot(has);
+            if (b == 0ull || n_items + 64u > kPoolCap) break;
+            if (has) lp.items[n_items + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u))] = (uint16_t)(lane | ((uint32_t)j << 6));
+            n_items += (uint32_t)__popcll(b); j++;
+        }
+        if (n_items == 0u) break;
+        n_pairs += n_items;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+        // ---- test them
+        for (uint32_t r = 0; r < n_items; r += 64u, rounds++) {
+            const bool act = r + lane < n_items;
+            const uint32_t it = act ? (uint32_t)lp.items[r + lane] : lane;
+            const uint32_t src = it & 63u;
+            const int src4 = (int)(src << 2);
+            RayF ray;
+            ray.ox = lane_read(src4, L.ray.ox); ray.oy = lane_read(src4, L.ray.oy); ray.oz = lane_read(src4, L.ray.oz);
+            ray.dx = lane_read(src4, L.ray.dx); ray.dy = lane_read(src4, L.ray.dy); ray.dz = lane_read(src4, L.ray.dz);
+            ray.tnear = lane_read(src4, L.ray.tnear);
+            ray.tfar = SPHERES ? lane_read(src4, L.ray.tfar) : 0.0f;
+            const float tbest = lane_read(src4, L.best.t);
+            const int pi = __builtin_amdgcn_ds_bpermute(src4, first) + (int)(it >> 6);
+            bool hit = false;
+            unsigned long long key = 0ull;
+            v4f w; w.x = 0.0f; w.y = 0.0f; w.z = 1.0f; w.w = 0.0f;
+            if (act) {
+                v4f p0, p1, p2;
+                if (RESIDENT || pi < tv.n_lprims) { const int S = tv.prim_stride; p0 = tv.lprims[pi]; p1 = tv.lprims[S + pi]; p2 = tv.lprims[2 * S + pi]; }
+                else { p0 = tv.gprims[3 * pi]; p1 = tv.gprims[3 * pi + 1]; p2 = tv.gprims[3 * pi + 2]; }
+                const int gprim = __float_as_int(p0.w);
+                if (!SPHERES || __float_as_int(p1.w) == 0) {
+                    const float v0[3] = {p0.x, p0.y, p0.z}, v1[3] = {p1.x, p1.y, p1.z}, v2[3] = {p2.x, p2.y, p2.z};
+                    float t = 0.0f, U = 0.0f, V = 0.0f, S = 1.0f;
+                    hit = tri_test_raw(ray, tbest, v0, v1, v2, t, U, V, S);   // t > tnear >= 0: its bits order like the value
+                    w.x = U; w.y = V; w.z = S; w.w = t;
+                    key = ((unsigned long long)f2u(t) << 32) | (unsigned long long)(uint32_t)gprim;
+                } else {
+                    double td = 0.0;
+                    hit = sphere_test(ray, tv.spheres[__float_as_int(p2.w)], td);
+                    const float t = (float)td;                                // t >= tnear >= 0; a zero of either sign orders as +0
+                    w.w = t;
+                    key = ((unsigned long long)(t == 0.0f ? 0u : f2u(t)) << 32) | (unsigned long long)(uint32_t)gprim;
+                }
+                if (hit) (void)__hip_atomic_fetch_min(&lp.keys[src], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+            // (a wave's LDS operations complete in order: every pair's minimum has landed when the read below is issued)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+            if (hit && __hip_atomic_load(&lp.keys[src], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) == key) lp.win[src] = w;   // one winner per ray: a leaf holds a primitive once
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+    }
+    // ---- every owner picks up its result: the rule of trav_leaf_step on (t, gprim)
+    if (at_leaf) {
+        bool stop = false;
+        const unsigned long long key = lp.keys[lane];
+        if (key != ~0ull) {
+            lp.keys[lane] = ~0ull;
+            const int gprim = (int)(uint32_t)key;
+            const v4f w = lp.win[lane];
+            // (selects, as in trav_leaf_step: an any-hit ray only needs `gprim`)
+            const bool take = any_hit | (w.w < L.best.t) | ((w.w == L.best.t) & ((L.best.gprim < 0) | (gprim < L.best.gprim)));
+            L.best.t = take ? w.w : L.best.t; L.best.u = take ? w.x : L.best.u; L.best.v = take ? w.y : L.best.v;
+            L.best_S = take ? w.z : L.best_S; L.best.gprim = take ? gprim : L.best.gprim;
+            stop = any_hit;
+        }
+        L.cur = stop ? kDone : trav_pop<RESIDENT>(tv, L);
+    }
+    return rounds;
 }
 
 // STATS: developer instrumentation (LJ_EXTEND_STATS=1): wave-level step counts and the lanes active in them, summed into
@@ -243,9 +351,12 @@ template <bool STATS, bool RESIDENT, bool SPHERES>
 #ifndef LJ_EXT_GENERAL_OCC
 #define LJ_EXT_GENERAL_OCC 4
 #endif
-__global__ void __launch_bounds__(kBlock, (RESIDENT && !SPHERES && !STATS) ? LJ_EXT_RESIDENT_OCC : (STATS ? 4 : LJ_EXT_GENERAL_OCC)) k_extend(DScene sc, DQueue q, const DBlockState *blocks, uint32_t seg, uint32_t *work, const uint32_t *chunk_list, uint32_t parity, int stack, int lds_nodes, int lds_prims, int *spill, uint32_t refill_min, uint32_t min_descending, unsigned long long *stats) {
+__global__ void __launch_bounds__(kBlock, (RESIDENT && !SPHERES && !STATS) ? LJ_EXT_RESIDENT_OCC : (STATS ? 4 : LJ_EXT_GENERAL_OCC)) k_extend(DScene sc, DQueue q, const DBlockState *blocks, uint32_t seg, uint32_t *work, const uint32_t *chunk_list, uint32_t parity, int stack, int lds_nodes, int lds_prims, int *spill, uint32_t refill_min, uint32_t min_descending, unsigned long long *stats, uint32_t pool_at) {
     unsigned long long st_outer = 0, st_busy = 0, st_nodes = 0, st_node_lanes = 0, st_leaf = 0, st_leaf_lanes = 0, st_refill = 0, st_rays = 0;
     const TreeView tv = stage_tree(sc, stack, lds_nodes, lds_prims, spill, gridDim.x * kBlock, blockIdx.x * kBlock + threadIdx.x);
+#if LJ_EXT_POOL
+    const LeafPool lp = leaf_pool_at(pool_at);
+#endif
     // Persistent waves: the shade launch before this one listed the chunks (kChunk queue slots inside one of its
     // segments) that hold live paths.  Wave w starts with list entry w; if the list is longer than the grid has
     // waves, the rest is drawn from one grid-wide counter (which the shade launch preset to the number of waves), so
@@ -325,6 +436,14 @@ __global__ void __launch_bounds__(kBlock, (RESIDENT && !SPHERES && !STATS) ? LJ_
             if (STATS) { st_nodes++; st_node_lanes += __popcll(dm); }
             if (descending) trav_node_step<RESIDENT>(tv, L);
         }
+#if LJ_EXT_POOL
+        // ... then the wave tests the primitives of all those leaves together, 64 (ray, primitive) pairs at a time
+        {
+            uint32_t n_pairs;
+            const uint32_t rounds = trav_leaf_pool<RESIDENT, SPHERES>(tv, lp, L, busy && L.cur < 0, phase == 0, n_pairs);
+            if (STATS) { st_leaf += rounds; st_leaf_lanes += n_pairs; }
+        }
+#else
         if (STATS) {
             const bool at_leaf = busy && L.cur < 0;
             int cnt = at_leaf ? ((~L.cur) & 7) + 1 : 0, mx = cnt, sum = cnt;
@@ -333,6 +452,7 @@ __global__ void __launch_bounds__(kBlock, (RESIDENT && !SPHERES && !STATS) ? LJ_
         }
         // ... then all of them test their leaf together
         if (busy && L.cur < 0) trav_leaf_step<RESIDENT, SPHERES>(tv, L, phase == 0);
+#endif
         // ---- ray finished?
         if (STATS) st_rays += __popcll(__ballot(busy && L.cur == kDone));
         if (busy && L.cur == kDone) {
@@ -530,18 +650,44 @@ __global__ void __launch_bounds__(kBlock) k_resolve(DPass pass, uint32_t n_pixel
 struct RayIO { float org[3]; float tnear; float dir[3]; float tfar; };
 struct HitIO { float t, u, v; int32_t shape_id, prim_id; };
 
-__global__ void __launch_bounds__(kBlock) k_trace_rays(DScene sc, const RayIO *rays, long long n, HitIO *hits, unsigned char *occ, int stack, int lds_nodes, int lds_prims, int *spill) {
+// (wave-complete iterations over the rays and the same two phases as k_extend — inner nodes lane by lane, leaves pooled — so that the
+// parity tests of intersect() / occluded() hold the pooled leaf phase to the oracle, bit for bit)
+__global__ void __launch_bounds__(kBlock) k_trace_rays(DScene sc, const RayIO *rays, long long n, HitIO *hits, unsigned char *occ, int stack, int lds_nodes, int lds_prims, int *spill, uint32_t pool_at) {
     const TreeView tv = stage_tree(sc, stack, lds_nodes, lds_prims, spill, gridDim.x * kBlock, blockIdx.x * kBlock + threadIdx.x);
-    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
+#if LJ_EXT_POOL
+    const LeafPool lp = leaf_pool_at(pool_at);
+#endif
+    for (long long i0 = (long long)blockIdx.x * kBlock; i0 < n; i0 += (long long)gridDim.x * kBlock) {
+        const long long i = i0 + threadIdx.x;
+        const bool act = i < n;
         LaneTrav L;
-        L.ray.ox = rays[i].org[0]; L.ray.oy = rays[i].org[1]; L.ray.oz = rays[i].org[2];
-        L.ray.dx = rays[i].dir[0]; L.ray.dy = rays[i].dir[1]; L.ray.dz = rays[i].dir[2];
-        trav_begin(L, rays[i].tnear, rays[i].tfar);
+        L.ray.ox = 0.0f; L.ray.oy = 0.0f; L.ray.oz = 0.0f; L.ray.dx = 0.0f; L.ray.dy = 0.0f; L.ray.dz = 1.0f;
+        if (act) {
+            L.ray.ox = rays[i].org[0]; L.ray.oy = rays[i].org[1]; L.ray.oz = rays[i].org[2];
+            L.ray.dx = rays[i].dir[0]; L.ray.dy = rays[i].dir[1]; L.ray.dz = rays[i].dir[2];
+        }
+        trav_begin(L, act ? rays[i].tnear : 0.0f, act ? rays[i].tfar : 0.0f);
+        if (!act) L.cur = kDone;
+#if LJ_EXT_POOL
+        for (;;) {
+            for (;;) {
+                const bool descending = L.cur >= 0 && L.cur != kDone;
+                if (__ballot(descending) == 0ull) break;
+                if (descending) trav_node_step<false>(tv, L);
+            }
+            const bool at_leaf = L.cur < 0;
+            if (__ballot(at_leaf) == 0ull) break;
+            uint32_t n_pairs;
+            (void)trav_leaf_pool<false, true>(tv, lp, L, at_leaf, occ != nullptr, n_pairs);
+        }
+#else
         while (L.cur != kDone) {
             while (L.cur >= 0 && L.cur != kDone) trav_node_step<false>(tv, L);
             if (L.cur < 0) trav_leaf_step<false, true>(tv, L, occ != nullptr);
         }
+#endif
         trav_finish(L);
+        if (!act) continue;
         if (occ) occ[i] = L.best.gprim >= 0 ? 1 : 0;
         else {
             HitIO o; o.t = 0; o.u = 0; o.v = 0; o.shape_id = -1; o.prim_id = -1;
@@ -634,7 +780,8 @@ ExtendConfig extend_config(int n_nodes, int n_prims, int bvh_depth, int n_sphere
     // LDS image: small scenes (which may become fully resident) get 16 stack levels and up to 40 KiB; for the others 12
     // levels + 24 KiB (the top ~100 nodes) do as well as 16 + 40 (sponza -1 %, disney_bsdf -4 %; 64 KiB: +30 % — it crowds
     // out the other workgroups of the CU)
-    int cap = n_prims <= 256 ? 16 : 12, kib = n_prims <= 256 ? 40 : 24;
+    // (the leaf pools of k_extend take another 8 KiB per workgroup)
+    int cap = n_prims <= 256 ? 16 : 12, kib = n_prims <= 256 ? (LJ_EXT_POOL ? 32 : 40) : 24;
     if (const char *e = getenv("LJ_TUNE_EXT_STACK")) cap = atoi(e);
     if (const char *e = getenv("LJ_TUNE_EXT_LDS_KB")) kib = atoi(e);
     c.stack = need < cap ? need : cap;
@@ -649,10 +796,10 @@ ExtendConfig extend_config(int n_nodes, int n_prims, int bvh_depth, int n_sphere
     c.resident = (c.lds_nodes == n_nodes && c.lds_prims == n_prims && c.spill_levels == 0 && c.stack + 1 <= 16) ? 1 : 0;
     if (c.resident) c.stack += 1;
     c.smem = (size_t)c.stack * kBlock * 4 + (size_t)c.lds_nodes * 112 + (size_t)c.lds_prims * 48;
-    // tuned on MI355X (tools/tune.sh): when the tree is LDS-resident a node step is cheap and waiting for the last
-    // descending lane costs little; with nodes in L2 the leaf phase starts once fewer than 24 lanes still descend
-    // (16 ... 28 are within 2 % of each other on sponza and disney_bsdf; 8: +7 %, 32: +3 %)
-    c.refill_min = 8; c.min_descending = (n_nodes <= c.lds_nodes) ? 1 : 24;
+    // tuned on MI355X (tools/pool_probe.sh): when the tree is LDS-resident a node step is cheap and waiting for the last
+    // descending lane costs little; with nodes in L2 the (pooled) leaf phase starts once fewer than 32 lanes still descend
+    // (sponza / disney_bsdf at 64 spp: 16: 65.2 / 30.6 ms, 24: 64.2 / 30.0, 32: 63.2 / 29.7, 40: 63.3 / 30.3, 48: 67.8 / 31.9)
+    c.refill_min = 8; c.min_descending = (n_nodes <= c.lds_nodes) ? 1 : (LJ_EXT_POOL ? 32 : 24);
     return c;
 }
 int max_stack_depth() { return 40; }  // inner levels; the builder's own cap is 38
@@ -675,9 +822,12 @@ ShadeConfig shade_config(size_t n_prims, size_t n_materials, size_t n_lights, si
     return c;
 }
 
+// LDS of an extend launch: the traversal image, then the leaf pools of its four waves
+size_t extend_smem(const ExtendConfig &cfg) { return ((cfg.smem + 15) & ~(size_t)15) + (LJ_EXT_POOL ? (kBlock / 64) * kWavePoolBytes : 0); }
 void launch_extend(const DScene &sc, const DQueue &q, const DBlockState *blocks, uint32_t grid, uint32_t seg, uint32_t *work, const uint32_t *chunk_list, uint32_t parity, const ExtendConfig &cfg, int *spill, unsigned long long *stats, hipStream_t s) {
     auto launch = [&](auto kernel) {
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), cfg.smem, s, sc, q, blocks, seg, work, chunk_list, parity, cfg.stack, cfg.lds_nodes, cfg.lds_prims, spill, cfg.refill_min, cfg.min_descending, stats);
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), extend_smem(cfg), s, sc, q, blocks, seg, work, chunk_list, parity, cfg.stack, cfg.lds_nodes, cfg.lds_prims, spill, cfg.refill_min, cfg.min_descending, stats,
+                           (uint32_t)((cfg.smem + 15) & ~(size_t)15));
     };
     const int variant = (stats ? 4 : 0) | (cfg.resident ? 2 : 0) | (cfg.spheres ? 1 : 0);
     switch (variant) {
@@ -741,7 +891,7 @@ void launch_volpath(const DScene &sc, const DPass &pass, uint32_t n_samples, uns
     else hipLaunchKernelGGL(k_volpath3, dim3(grid), dim3(kBlock), cfg.smem, s, sc, pass, n_samples, bounce_counter, cfg.stack, cfg.lds_nodes, cfg.lds_prims, spill);
 }
 void launch_trace_rays(const DScene &sc, const void *rays, long long n, void *hits, unsigned char *occ, const ExtendConfig &cfg, int *spill, int grid, hipStream_t s) {
-    hipLaunchKernelGGL(k_trace_rays, dim3(grid), dim3(kBlock), cfg.smem, s, sc, (const RayIO *)rays, n, (HitIO *)hits, occ, cfg.stack, cfg.lds_nodes, cfg.lds_prims, spill);
+    hipLaunchKernelGGL(k_trace_rays, dim3(grid), dim3(kBlock), extend_smem(cfg), s, sc, (const RayIO *)rays, n, (HitIO *)hits, occ, cfg.stack, cfg.lds_nodes, cfg.lds_prims, spill, (uint32_t)((cfg.smem + 15) & ~(size_t)15));
 }
 
 } // namespace ljd
