@@ -48,6 +48,7 @@ struct Builder {
     size_t refs_total;
     float root_area;
     float alpha = 1e-5f, gain = 1.0f;   // overlap threshold (fraction of the root's area) and the factor a spatial split has to beat the object split by
+    float prim_cost = 1.2f;            // SAH: cost of a primitive test against 1.0 for a box test (LJ_TUNE_PRIM_COST)
 
     static void pad(Box &b) {     // the builder's box padding (flatten.cpp): a box test may accept a box the exact ray misses, never the reverse
         for (int k = 0; k < 3; k++) {
@@ -183,8 +184,8 @@ struct Builder {
                 left.assign(refs.begin(), refs.begin() + count / 2); right.assign(refs.begin() + count / 2, refs.end());   // all centroids coincide: halve the list
             } else {
                 // 1.0 box-test cost vs 1.2 primitive-test cost, both children boxes are tested in the parent
-                const float split_cost = 1.0f * box.half_area() + best_cost * 1.2f;
-                if (count <= max_leaf && leaf_cost * 1.2f <= split_cost) return make_leaf();
+                const float split_cost = 1.0f * box.half_area() + best_cost * prim_cost;
+                if (count <= max_leaf && leaf_cost * prim_cost <= split_cost) return make_leaf();
                 const float c0 = cbox.lo[best_axis], c1 = cbox.hi[best_axis], scale = kBins / (c1 - c0);
                 for (const Ref &r : refs) {
                     const float c = 0.5f * (r.box.lo[best_axis] + r.box.hi[best_axis]);
@@ -228,6 +229,7 @@ void build_bvh(const std::vector<BuildPrim> &prims, int max_leaf, int max_depth,
     b.root_area = rootb.half_area();
     if (const char *e = getenv("LJ_TUNE_SBVH_ALPHA")) b.alpha = (float)atof(e);
     if (const char *e = getenv("LJ_TUNE_SBVH_GAIN")) b.gain = (float)atof(e);
+    if (const char *e = getenv("LJ_TUNE_PRIM_COST")) b.prim_cost = (float)atof(e);
     b.order.reserve((size_t)n + n / 3);
     b.tmp.reserve(2 * (size_t)n);
     const int root = b.build(refs, 0);
