@@ -137,6 +137,7 @@ struct DScene {
     const int32_t *shape_media;      // per shape: interior, exterior medium id (-1: none)
     int32_t cam_medium, max_null_collisions;
     int32_t has_heterogeneous_medium;   // some medium is a grid volume (picks the k_volpath instantiation)
+    int32_t vol_path_version;           // RenderOptions::vol_path_version (render.cpp:111-123): 1 and 2 are estimators of their own
     // tiny scenes only (dscan.h): the flat leaf table; n_scan_leaves is a multiple of 4, 0 when the scene has none
     const DScanLeaf *scan_leaves; int32_t n_scan_leaves;
 };

@@ -189,10 +189,78 @@ LJ_HD f3 vol_nee(const DScene &sc, Tracer &tr, VolRng &rng, f3 p, int current_me
     return contrib * vdiv3(n2, n2 + d2);
 }
 
-// vol_path_tracing (vol_path_tracing.h:503-869); see oracle/lj_oracle.cpp for the list of reference quirks kept
+// vol_path_tracing_1 (vol_path_tracing.h:6-41): absorption only — a directly visible emitter through the exterior medium of its surface
+template <class Tracer>
+LJ_HD f3 vol_path_sample_1(const DScene &sc, Tracer &tr, int x, int y, VolRng &rng) {
+    const float jy = vrnd(rng), jx = vrnd(rng);
+    const f3 org = ld3(sc.cam.org), dir = camera_primary_dir(sc.cam, x, y, jx, jy);
+    float t, hu, hv; int gprim;
+    if (!tr.closest(org, dir, 0.0f, INFINITY, t, hu, hv, gprim)) return mk3(0, 0, 0);   // (sample_primary's tnear: camera.cpp:46)
+    const DVertex vertex = build_vertex(sc, org, dir, t, hu, hv, gprim, 0.0f);
+    const int exterior = sc.shape_media[2 * sc.prims[gprim].shape_id + 1];
+    if (exterior == -1) return mk3(0, 0, 0);
+    const float t_hit = length(vertex.position - org);
+    f3 sigma_s, sigma_a; get_sigmas(sc, sc.media[exterior], vertex.position, sigma_s, sigma_a);
+    const f3 transmittance = vexp3(-(sigma_a * t_hit));
+    f3 Le = mk3(0, 0, 0);
+    if (vertex.light_id >= 0) Le = light_emission(sc, sc.lights[vertex.light_id], -dir, vertex.gn);
+    return transmittance * Le;
+}
+
+// vol_path_tracing_2 (vol_path_tracing.h:46-147): one monochromatic homogeneous medium, single scattering, free flight on the red channel
+// (oracle/lj_oracle.cpp vol_path_tracing_2 lists what is kept of the reference's reading of an empty optional)
+template <class Tracer>
+LJ_HD f3 vol_path_sample_2(const DScene &sc, Tracer &tr, int x, int y, VolRng &rng) {
+    const float jy = vrnd(rng), jx = vrnd(rng);
+    const f3 org = ld3(sc.cam.org), dir = camera_primary_dir(sc.cam, x, y, jx, jy);
+    float th, hu, hv; int gprim;
+    const bool hit = tr.closest(org, dir, 0.0f, INFINITY, th, hu, hv, gprim);
+    DVertex vertex;
+    float t_hit = INFINITY;
+    int medium_id = sc.cam_medium;
+    if (hit) { vertex = build_vertex(sc, org, dir, th, hu, hv, gprim, 0.0f); t_hit = length(vertex.position - org); medium_id = sc.shape_media[2 * sc.prims[gprim].shape_id + 1]; }
+    if (medium_id < 0) return mk3(0, 0, 0);
+    const DMedium &med = sc.media[medium_id];
+    f3 sigma_s, sigma_a; get_sigmas(sc, med, hit ? vertex.position : org, sigma_s, sigma_a);
+    const f3 sigma_t = sigma_s + sigma_a;
+    const float u = vrnd(rng);
+    const float t = -logf(1.0f - u) / sigma_t.x;
+    if (t < t_hit) {
+        const f3 transmittance = vexp3(-(sigma_t * t)), trans_pdf = transmittance * sigma_t;
+        const f3 p = org + dir * t;
+        const float lu0 = vrnd(rng), lu1 = vrnd(rng), light_w = vrnd(rng), shape_w = vrnd(rng);
+        const int light_id = sample_cdf(sc.light_cdf, sc.n_lights, light_w);
+        const DLight &Lt = sc.lights[light_id];
+        const LightSample pl = sample_point_on_light(sc, Lt, p, lu0, lu1, shape_w);
+        // (direction and distance from the double sample point, as in vol_nee)
+        const double dx = pl.dpos[0] - (double)p.x, dy = pl.dpos[1] - (double)p.y, dz = pl.dpos[2] - (double)p.z;
+        const double dist_d = sqrt(dx * dx + dy * dy + dz * dz);
+        const f3 dir_light = mk3((float)(dx / dist_d), (float)(dy / dist_d), (float)(dz / dist_d));
+        const float dist = (float)dist_d;
+        const float rho = phase_eval(med, -dir, dir_light);
+        const f3 Le = light_emission(sc, Lt, -dir_light, pl.normal);
+        const f3 exp_term = vexp3(-(sigma_t * dist));
+        float st, su, sv; int sg;
+        const float visibility = tr.closest(p, dir_light, sc.eps, (float)((1.0 - (double)sc.eps) * dist_d), st, su, sv, sg) ? 0.0f : 1.0f;
+        const float jacobian = fabsf(dot(dir_light, pl.normal)) / (float)(dist_d * dist_d) * visibility;
+        const f3 L_s1 = Le * rho * exp_term * jacobian;
+        const float L_s1_pdf = Lt.pmf * pdf_point_on_light(sc, Lt, pl.position, pl.normal, p);
+        return vdiv3(transmittance, trans_pdf) * sigma_s * (L_s1 / L_s1_pdf);
+    }
+    const f3 transmittance = vexp3(-(sigma_t * t_hit));   // (the pdf is the same expression: the ratio is 1, or 0 / 0 once it underflows)
+    f3 Le = mk3(0, 0, 0);
+    if (vertex.light_id >= 0) Le = light_emission(sc, sc.lights[vertex.light_id], -dir, vertex.gn);
+    return vdiv3(transmittance, transmittance) * Le;
+}
+
+// vol_path_tracing (vol_path_tracing.h:503-869); see oracle/lj_oracle.cpp for the list of reference quirks kept.  Versions 3, 4 and 5 of
+// the reference return this function's result in their first statement (vol_path_tracing.h:880, 1052, 1297).
 template <class Tracer>
 LJ_HD f3 vol_path_sample(const DScene &sc, Tracer &tr, int x, int y, uint64_t stream, uint64_t seed, uint32_t &bounces_out) {
     VolRng rng; rng.inc = pcg32_inc(stream); rng.state = pcg32_init(stream, seed);
+    bounces_out = 0;
+    if (sc.vol_path_version == 1) return vol_path_sample_1(sc, tr, x, y, rng);
+    if (sc.vol_path_version == 2) return vol_path_sample_2(sc, tr, x, y, rng);
     const float jy = vrnd(rng), jx = vrnd(rng);
     f3 org = ld3(sc.cam.org), dir = camera_primary_dir(sc.cam, x, y, jx, jy);
     float spread = 0.0f;   // RayDifferential{0, 0}: only `spread` ever changes (ray.h:45-66 with radius 0)

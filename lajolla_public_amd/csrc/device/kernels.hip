@@ -748,7 +748,8 @@ __device__ __forceinline__ void volpath_body(const DScene &sc, const DPass &pass
         const uint32_t p = s / pass.spp, k = s - p * pass.spp;
         const uint32_t pixel = pass.pixel_list[p];
         uint32_t nb = 0;
-        const f3 rad = vol_path_sample(sc, tr, (int)(pixel % (uint32_t)sc.cam.width), (int)(pixel / (uint32_t)sc.cam.width), (uint64_t)pixel * pass.spp + k, pass.seed, nb);
+        f3 rad = vol_path_sample(sc, tr, (int)(pixel % (uint32_t)sc.cam.width), (int)(pixel / (uint32_t)sc.cam.width), (uint64_t)pixel * pass.spp + k, pass.seed, nb);
+        if (!(isfinite(rad.x) && isfinite(rad.y) && isfinite(rad.z))) rad = mk3(0, 0, 0);   // render.cpp:138-141: a non-finite sample is left out
         float *o = pass.sample_rgb + 3ull * s;
         o[0] = rad.x; o[1] = rad.y; o[2] = rad.z;
         bounces += nb;

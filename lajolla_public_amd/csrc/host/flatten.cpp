@@ -84,6 +84,7 @@ ljd::DScene FlatScene::host_view() const {
     s.init_spread = 0.25f / (float)std::max(cam.width, cam.height);
     s.media = media.data(); s.n_media = (int)media.size(); s.volume_data = volume_data.data(); s.shape_media = shape_media.data();
     s.cam_medium = cam_medium; s.max_null_collisions = max_null_collisions;
+    s.vol_path_version = vol_path_version;
     s.has_heterogeneous_medium = 0;
     for (const auto &m : media) if (m.kind == LJ_MEDIUM_HETEROGENEOUS) s.has_heterogeneous_medium = 1;
     s.scan_leaves = scan_leaves.empty() ? nullptr : scan_leaves.data(); s.n_scan_leaves = (int32_t)scan_leaves.size();

@@ -1581,8 +1581,76 @@ Spectrum vol_nee(const OScene &scene, pcg32_state &rng, Vector3 p, int current_m
     return vmul(contrib, w);
 }
 
-// vol_path_tracing (vol_path_tracing.h:503-869), the final renderer; the earlier versions (vol_path_tracing_1..5, the
-// homework's intermediate steps) are special cases of it and are rendered with it — same expectation, more variance.
+// vol_path_tracing_1 (vol_path_tracing.h:6-41): absorption only, a directly visible emitter seen through the exterior medium of the
+// surface it sits on.  (The primary ray keeps sample_primary's tnear of 0; only the final version moves it to the epsilon.)
+Spectrum vol_path_tracing_1(const OScene &scene, int x, int y, pcg32_state &rng, Counters *cnt) {
+    const LjCamera &cam = scene.d.camera;
+    Real jy = next_pcg32_real(rng);   // g++ evaluates the constructor arguments right to left
+    Real jx = next_pcg32_real(rng);
+    Ray ray = sample_primary(scene, Vector2{(x + jx) / cam.width, (y + jy) / cam.height});
+    if (cnt) cnt->samples++;
+    PathVertex vertex;
+    if (!intersect(scene, ray, RayDifferential{0, 0}, vertex, cnt)) return {0, 0, 0};
+    const int exterior = scene.shapes[vertex.shape_id].exterior_medium_id;   // (PathVertex::exterior_medium_id, intersection.cpp:60)
+    if (exterior == -1) return {0, 0, 0};
+    const LjMedium &med = scene.d.media[exterior];
+    const Real t_hit = distance(vertex.position, ray.org);
+    const Vector3 sigma_a = get_sigma_a(med, vertex.position);
+    const Spectrum transmittance = vexp(-(sigma_a * t_hit));
+    Spectrum Le{0, 0, 0};
+    if (scene.shapes[vertex.shape_id].area_light_id >= 0) Le = vertex_emission(scene, vertex, -ray.dir);
+    return vmul(transmittance, Le);
+}
+
+// vol_path_tracing_2 (vol_path_tracing.h:46-147): one monochromatic homogeneous medium, single scattering; free-flight sampling on
+// the red channel.  The reference reads `*vertex_` before it knows the ray hit anything (:59); for a ray that leaves the scene the
+// cross sections are looked up at the ray origin here (a homogeneous medium — the only kind this version is meant for — has no
+// position dependence), and the `t >= t_hit` arm cannot be reached then (t_hit is infinite).
+Spectrum vol_path_tracing_2(const OScene &scene, int x, int y, pcg32_state &rng, Counters *cnt) {
+    const LjCamera &cam = scene.d.camera;
+    Real jy = next_pcg32_real(rng);
+    Real jx = next_pcg32_real(rng);
+    Ray ray = sample_primary(scene, Vector2{(x + jx) / cam.width, (y + jy) / cam.height});
+    if (cnt) cnt->samples++;
+    PathVertex vertex;
+    const bool hit = intersect(scene, ray, RayDifferential{0, 0}, vertex, cnt);
+    const int medium_id = hit ? scene.shapes[vertex.shape_id].exterior_medium_id : cam.medium_id;
+    if (medium_id < 0) return {0, 0, 0};   // (scene.media[-1] in the reference: undefined; nothing sensible to restate)
+    const Real t_hit = hit ? distance(vertex.position, ray.org) : std::numeric_limits<Real>::infinity();
+    const LjMedium &med = scene.d.media[medium_id];
+    const Vector3 at = hit ? vertex.position : ray.org;
+    const Vector3 sigma_s = get_sigma_s(med, at), sigma_a = get_sigma_a(med, at), sigma_t = sigma_s + sigma_a;
+    const Real u = next_pcg32_real(rng);
+    const Real t = -std::log(1 - u) / sigma_t.x;
+    if (t < t_hit) {
+        const Spectrum transmittance = vexp(-(sigma_t * t)), trans_pdf = vmul(transmittance, sigma_t);
+        const Vector3 p = ray.org + ray.dir * t;
+        Vector2 light_uv; light_uv.x = next_pcg32_real(rng); light_uv.y = next_pcg32_real(rng);
+        const Real light_w = next_pcg32_real(rng);
+        const Real shape_w = next_pcg32_real(rng);
+        const int light_id = sample_1d(scene.light_dist, light_w);
+        const PointAndNormal pl = sample_point_on_light(scene, light_id, p, light_uv, shape_w);
+        const Vector3 dir_light = normalize(pl.position - p);
+        const Real rho = phase_eval(med, -ray.dir, dir_light);
+        const Spectrum Le = light_emission(scene, light_id, -dir_light, Real(0), pl);
+        const Real dist = distance(p, pl.position);
+        const Spectrum exp_term = vexp(-(sigma_t * dist));
+        const Real eps = shadow_epsilon(scene);
+        Real visibility = 1;
+        if (occluded(scene, Ray{p, dir_light, eps, (1 - eps) * distance(pl.position, p)}, cnt)) visibility = 0;
+        const Real jacobian = std::fabs(dot(dir_light, pl.normal)) / distance_squared(p, pl.position) * visibility;
+        const Spectrum L_s1 = vmul(Le * rho, exp_term) * jacobian;
+        const Real L_s1_pdf = scene.light_dist.pmf[light_id] * pdf_point_on_light(scene, light_id, pl, p);
+        return vmul(vmul(vdiv(transmittance, trans_pdf), sigma_s), L_s1 / L_s1_pdf);
+    }
+    const Spectrum transmittance = vexp(-(sigma_t * t_hit));   // (trans_pdf is the same expression: the ratio is 1, or 0/0 once it underflows)
+    Spectrum Le{0, 0, 0};
+    if (scene.shapes[vertex.shape_id].area_light_id >= 0) Le = vertex_emission(scene, vertex, -ray.dir);
+    return vmul(vdiv(transmittance, transmittance), Le);
+}
+
+// vol_path_tracing (vol_path_tracing.h:503-869), the final renderer.  vol_path_tracing_3 / _4 / _5 return its result in their first
+// statement (vol_path_tracing.h:880, 1052, 1297), so versions 3 ... 6 (and an unset version, render.cpp:111) are this function.
 // Reference quirks kept: a ray that leaves the scene from vacuum returns ZERO, not the radiance gathered so far (:626);
 // an emitter reached by phase / BSDF sampling is weighted with a geometry term of the wrong sign, i.e. zero for a
 // front-facing hit (:688-695); no pdf > 0 check after BSDF sampling (:836-841).  nee_p_cache is read before it is
@@ -1964,8 +2032,13 @@ int oracle_render(void *sv, const OracleRenderArgs *a, double *rgb, double *per_
                 for (int sidx = 0; sidx < spp; sidx++) {
                     int st = 0;
                     if (a->rng_mode == 0) rng = init_pcg32(((uint64_t)y * w + x) * (uint64_t)spp + sidx, seed);
-                    Spectrum L = s->d.options.integrator == LJ_INTEGRATOR_VOLPATH ? vol_path_tracing(*s, x, y, rng, a->max_depth, a->use_max_depth != 0, &cnt, &st)
-                                                                                   : path_tracing(*s, x, y, rng, a->max_depth, a->use_max_depth != 0, &cnt, &st);
+                    Spectrum L;
+                    if (s->d.options.integrator == LJ_INTEGRATOR_VOLPATH) {   // vol_path_render, render.cpp:111-141
+                        const int version = s->d.options.vol_path_version;
+                        L = version == 1 ? vol_path_tracing_1(*s, x, y, rng, &cnt) : version == 2 ? vol_path_tracing_2(*s, x, y, rng, &cnt)
+                                         : vol_path_tracing(*s, x, y, rng, a->max_depth, a->use_max_depth != 0, &cnt, &st);
+                        if (!(std::isfinite(L.x) && std::isfinite(L.y) && std::isfinite(L.z))) L = {0, 0, 0};   // render.cpp:138-141: non-finite samples are left out
+                    } else L = path_tracing(*s, x, y, rng, a->max_depth, a->use_max_depth != 0, &cnt, &st);
                     if (st) status.store(st);
                     radiance += L;
                     if (per_sample && inside) {

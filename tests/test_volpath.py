@@ -1,10 +1,12 @@
-"""The volumetric path tracer (vol_path_tracing.h:503-869 with next_event_estimation_final :299-494).
+"""The volumetric path tracers (vol_path_tracing.h): the final one (:503-869 with next_event_estimation_final :299-494)
+and the two earlier estimators the reference still selects by the scene's `version` (render.cpp:111-123): vol_path_tracing_1 (:6-41,
+absorption only) and vol_path_tracing_2 (:46-147, single scattering).  Versions 3, 4 and 5 return the final version's result in their
+first statement (:880, :1052, :1297), so they ARE the final version.
 
-The reference's earlier versions (vol_path_tracing_1..5, selected by the scene's `version`) are special cases of the
-final one and are rendered with it.  Parity with the reference is statistical by SURVEY's own bar — it cannot be run here
-(Embree) and contains undefined behaviour — so the chain is: reference medium / phase / volume functions -> oracle (known
-answers, tests/test_oracle_golden.py) -> an analytic case -> device code against the oracle under identical pcg32 streams,
-where float and double walk the same path until a discrete decision flips."""
+Parity with the reference is statistical by SURVEY's own bar — it cannot be run here (Embree) and contains undefined behaviour — so the
+chain is: reference medium / phase / volume functions -> oracle (known answers, tests/test_oracle_golden.py) -> an analytic case ->
+device code against the oracle under identical pcg32 streams, where float and double walk the same path until a discrete decision
+flips; the handout renders (tests/test_handout_renders.py: volpath_1 ... volpath_6) pin the oracle end to end."""
 import os
 
 import numpy as np
@@ -14,7 +16,7 @@ import lajolla_public_amd as lj
 from lajolla_public_amd import _abi
 from helpers import Oracle, Twin, ROOT
 
-CASES = [("volpath_test1", (240, 240, 272, 272)), ("volpath_test3", (200, 200, 264, 264)), ("volpath_test5", (200, 200, 264, 264)),
+CASES = [("volpath_test1", (240, 240, 272, 272)), ("volpath_test2", (200, 200, 264, 264)), ("volpath_test3", (200, 200, 264, 264)), ("volpath_test5", (200, 200, 264, 264)),
          ("volpath_test6", (200, 200, 264, 264)), ("vol_cbox_teapot", (200, 250, 264, 314)), ("hetvol", (350, 250, 414, 314)),
          ("hetvol_colored", (350, 250, 414, 314))]
 
@@ -48,6 +50,33 @@ def test_absorbing_medium_matches_the_closed_form():
     le = np.array(list(hs.desc.lights[0].intensity))
     expect = np.exp(-np.array(list(m.sigma_a)) * 2.0) * le    # camera at z = -3, unit sphere at the origin
     assert np.allclose(mean, expect, rtol=2e-2)
+
+
+def test_versions_one_and_two_are_estimators_of_their_own():
+    """render.cpp:111-123 picks vol_path_tracing_1 / _2 for version 1 / 2: other samples than the final version draws (other random
+    numbers, red-channel free flight), the same image in expectation where their assumptions hold (volpath_test1 / 2 are built for them)."""
+    for name, version, crop in (("volpath_test1", 1, (240, 240, 272, 272)), ("volpath_test2", 2, (224, 224, 288, 288))):
+        hs = vol_scene(name)
+        assert hs.desc.options.vol_path_version == version
+        o = Oracle(hs)
+        rc, img_v, ps_v, _ = o.render(spp=64, crop=crop, per_sample=True)
+        hs.desc.options.vol_path_version = 6
+        o6 = Oracle(hs)
+        rc6, img_6, ps_6, _ = o6.render(spp=64, crop=crop, per_sample=True)
+        assert rc == 0 and rc6 == 0
+        if version == 2: assert not np.array_equal(ps_v, ps_6)
+        x0, y0, x1, y1 = crop
+        a, b = img_v[y0:y1, x0:x1].mean(axis=(0, 1)), img_6[y0:y1, x0:x1].mean(axis=(0, 1))
+        assert np.allclose(a, b, rtol=0.05, atol=1e-3), (name, a, b)
+        # an unset version (0) and versions 3 ... 6 are the final estimator, sample for sample
+        for v in (0, 3, 4, 5):
+            hs.desc.options.vol_path_version = v
+            rcv, _, ps_x, _ = Oracle(hs).render(spp=2, crop=crop, per_sample=True)
+            assert rcv == 0 and np.array_equal(ps_x, o6.render(spp=2, crop=crop, per_sample=True)[2])
+        # the host twin of the device code takes the same branch
+        hs.desc.options.vol_path_version = version
+        pt, _ = Twin(hs).render_samples(crop, 8)
+        check_samples(pt, Oracle(hs).render(spp=8, crop=crop, per_sample=True)[2])
 
 
 @pytest.mark.parametrize("name,crop", CASES)

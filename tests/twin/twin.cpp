@@ -130,7 +130,8 @@ void twin_render_samples(void *tv, int spp, int max_depth, int use_max_depth, ui
                 HostTracer tr{sc};
                 const uint32_t pixel = pixels[s / spp];
                 uint32_t nb = 0;
-                const f3 r = vol_path_sample(sc, tr, (int)(pixel % (uint32_t)w), (int)(pixel / (uint32_t)w), (uint64_t)pixel * spp + (s % spp), pass.seed, nb);
+                f3 r = vol_path_sample(sc, tr, (int)(pixel % (uint32_t)w), (int)(pixel / (uint32_t)w), (uint64_t)pixel * spp + (s % spp), pass.seed, nb);
+                if (!(std::isfinite(r.x) && std::isfinite(r.y) && std::isfinite(r.z))) r = mk3(0, 0, 0);   // (volpath_body, kernels.hip)
                 out[3 * s] = r.x; out[3 * s + 1] = r.y; out[3 * s + 2] = r.z;
                 cnt.bounces += nb;
                 continue;
