@@ -227,6 +227,11 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
     // them: lanes would only time-slice the GPU (disney_bsdf 256 spp: 104 ms with one lane, 116 with two; a 64-spp render, which fits
     // the pool at once, is the other way round by 7 %)
     if (sc->scfg.variant >= 3) n_lanes = 1;   // (FeatDisney, FeatAll)
+    // a tree beyond the LDS image (nodes fetched through L2): one lane.  Its extend launches fill every CU (five workgroups of 30 KiB
+    // LDS and 92 VGPRs each), so the lanes' kernels queue up behind one another instead of running side by side (tools/lanes_sweep.sh,
+    // sponza 256 spp: 202.5 ms with one lane, 208.8 with four)
+    const bool large_tree = ds.n_nodes > sc->ecfg.lds_nodes;
+    if (large_tree) n_lanes = 1;
     if (const char *e = getenv("LJ_TUNE_LANES")) n_lanes = (uint32_t)std::min((int)kMaxLanes, std::max(1, atoi(e)));
     uint32_t n_blocks = std::min<uint32_t>(kMaxBlocks, std::max<uint32_t>(n_lanes, std::min<uint32_t>((uint32_t)ctx->n_cus * blocks_per_cu, pool / 256)));
     n_blocks = (n_blocks / n_lanes) * n_lanes;
@@ -242,7 +247,10 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
     const uint32_t lane_chunks = lane_slots / 256u;
     const uint32_t ext_grid = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)ctx->n_cus * ext_per_cu, (lane_chunks + 3) / 4));
     // (the fused tail launches one workgroup per segment, so its overflow stacks are sized for the shade grid)
-    const bool use_tail = !timing && !xstats && ljd::tail_smem(sc->ecfg, sc->scfg) > 0 && !(getenv("LJ_TUNE_TAIL") && atoi(getenv("LJ_TUNE_TAIL")) == 0);
+    // (not for a large tree: the tail's lane-by-lane traversal — one workgroup per segment, leaves tested unpooled — is slower there than
+    // the extend / shade launches it replaces: tools/tail_sweep.sh, sponza 64 spp 60.4 -> 56.2 ms, disney_bsdf 256 spp 98.7 -> 97.2 without it)
+    bool use_tail = !timing && !xstats && !large_tree && ljd::tail_smem(sc->ecfg, sc->scfg) > 0;
+    if (const char *e = getenv("LJ_TUNE_TAIL")) use_tail = use_tail && atoi(e) != 0;
     uint64_t tail_num = 1, tail_den = 4;   // fuse once fewer than tail_num / tail_den of the slots hold a path
     if (const char *e = getenv("LJ_TUNE_TAIL_FRAC")) { tail_num = (uint64_t)std::max(1, atoi(e)); tail_den = 16; }
     const uint32_t spill_grid = std::max<uint32_t>(ext_grid, use_tail ? lane_blocks : 0u);

@@ -94,6 +94,7 @@ struct LaneTrav {
     HitRec best;     // for a triangle hit u, v hold the unnormalised barycentrics U, V until trav_finish divides by best_S
     float best_S;
     int cur, sp;
+    int held;        // a leaf this ray has reached but not tested yet (0: none) — see trav_hold
     uint32_t nqx, nqy, nqz;  // quarter index (0..5) holding the NEAR plane of each axis for this ray's direction signs
 };
 
@@ -109,7 +110,7 @@ __device__ __forceinline__ void trav_begin(LaneTrav &L, float tnear, float tfar)
     L.oix = L.ray.ox * L.ix; L.oiy = L.ray.oy * L.iy; L.oiz = L.ray.oz * L.iz;
     L.nqx = L.ix < 0.0f ? 3u : 0u; L.nqy = L.iy < 0.0f ? 4u : 1u; L.nqz = L.iz < 0.0f ? 5u : 2u;
     L.best.t = tfar; L.best.u = 0.0f; L.best.v = 0.0f; L.best.gprim = -1; L.best_S = 1.0f;
-    L.cur = 0; L.sp = 0;
+    L.cur = 0; L.sp = 0; L.held = 0;
 }
 __device__ __forceinline__ void trav_push(const TreeView &tv, LaneTrav &L, int v) {
     if (L.sp < tv.cap) tv.stack[L.sp * kBlock] = v;
@@ -118,7 +119,8 @@ __device__ __forceinline__ void trav_push(const TreeView &tv, LaneTrav &L, int v
 }
 template <bool RESIDENT = false>
 __device__ __forceinline__ int trav_pop(const TreeView &tv, LaneTrav &L) {
-    if (RESIDENT) {   // every level is in LDS: one read, no branch (and no global load for the scheduler to wait on)
+    // every level (of the lanes that pop here) is in LDS: one read, no branch (and no global load for the scheduler to wait on)
+    if (RESIDENT || __ballot(L.sp > tv.cap) == 0ull) {
         const int sp = L.sp > 0 ? L.sp - 1 : 0;
         const int v = tv.stack[sp * kBlock];
         const int r = L.sp > 0 ? v : kDone;
@@ -129,6 +131,22 @@ __device__ __forceinline__ int trav_pop(const TreeView &tv, LaneTrav &L) {
     L.sp--;
     if (L.sp < tv.cap) return tv.stack[L.sp * kBlock];
     return tv.spill[(uint32_t)(L.sp - tv.cap) * tv.spill_stride];
+}
+
+// A ray that reaches a leaf sets it aside and goes on with the next entry of its stack; it only has to wait for the wave's leaf phase when
+// it reaches a second one.  The lanes of a wave then spend more node steps together before the leaf phase (which finds fuller rounds), at
+// the price of the node steps a hit in the held leaf would have culled.  The closest hit is the minimum of (t, primitive id) over
+// everything the ray tests, so the order of the tests cannot change it.
+#ifndef LJ_EXT_HOLD
+#define LJ_EXT_HOLD 1
+#endif
+#ifndef LJ_EXT_HOLD_SHADOW
+#define LJ_EXT_HOLD_SHADOW 1   // any-hit rays hold a leaf too (0: they wait at their first leaf — a hit there ends them)
+#endif
+template <bool RESIDENT>
+__device__ __forceinline__ void trav_hold(const TreeView &tv, LaneTrav &L) {
+    L.held = L.cur;
+    L.cur = trav_pop<RESIDENT>(tv, L);
 }
 
 // the one barycentric division of a closest-hit query (dtrace.h tri_test: u = U * (1 / S))
@@ -144,21 +162,25 @@ __device__ __forceinline__ void csw(float &ta, int &ca, float &tb, int &cb) {  /
 }
 
 // one inner-node step: slab-test the four children, continue with the nearest one that is hit, push the others far-first.
-// RESIDENT: the whole tree and every stack level are in LDS (small scenes) — the step is then free of branches: the
-// three pushes store unconditionally and advance `sp` only for a hit, and the pop candidate is fetched with the node.
+// The stack part of the step is free of branches whenever the three pushes of every lane stay inside the LDS levels (always, when
+// the scene is RESIDENT — the whole tree and every stack level in LDS; else a wave-uniform test, which only a ray deeper than
+// `cap - 3` entries fails): the pushes store unconditionally and advance `sp` only for a hit, and the pop candidate is fetched with the node.
+#ifndef LJ_EXT_LDS_NODES
+#define LJ_EXT_LDS_NODES 1   // 0: a tree that is not fully LDS-resident is read through L1 / L2 only (no LDS copy of its top)
+#endif
 template <bool RESIDENT>
 __device__ __forceinline__ void trav_node_step(const TreeView &tv, LaneTrav &L) {
     v4f nx, ny, nz, fx, fy, fz, ch;
     const int i = L.cur;
     int popped = kDone;
-    if (RESIDENT || i < tv.n_lnodes) {
+    const bool fast = RESIDENT || __ballot(L.sp + 3 > tv.cap) == 0ull;
+    if (RESIDENT || (LJ_EXT_LDS_NODES && i < tv.n_lnodes)) {
         const LJ_LDS char *b = tv.lnodes + (uint32_t)i * 16u;
         const uint32_t S = tv.qstride;
         nx = *(const LJ_LDS v4f *)(b + L.nqx * S); fx = *(const LJ_LDS v4f *)(b + (3u - L.nqx) * S);
         ny = *(const LJ_LDS v4f *)(b + L.nqy * S); fy = *(const LJ_LDS v4f *)(b + (5u - L.nqy) * S);
         nz = *(const LJ_LDS v4f *)(b + L.nqz * S); fz = *(const LJ_LDS v4f *)(b + (7u - L.nqz) * S);
         ch = *(const LJ_LDS v4f *)(b + 6u * S);
-        if (RESIDENT) popped = tv.stack[(L.sp > 0 ? L.sp - 1 : 0) * kBlock];
     } else {
         const char *g = tv.gnodes;
         const uint32_t o = (uint32_t)i * 128u;
@@ -167,6 +189,7 @@ __device__ __forceinline__ void trav_node_step(const TreeView &tv, LaneTrav &L) 
         nz = *(const v4f *)(g + (o + L.nqz * 16u)); fz = *(const v4f *)(g + (o + (7u - L.nqz) * 16u));
         ch = *(const v4f *)(g + (o + 96u));
     }
+    if (fast) popped = tv.stack[(L.sp > 0 ? L.sp - 1 : 0) * kBlock];
     const float inf = __builtin_inff();
 
     float t0[4]; int c[4];
@@ -181,7 +204,7 @@ __device__ __forceinline__ void trav_node_step(const TreeView &tv, LaneTrav &L) 
     csw(t0[0], c[0], t0[1], c[1]); csw(t0[2], c[2], t0[3], c[3]);
     csw(t0[0], c[0], t0[2], c[2]); csw(t0[1], c[1], t0[3], c[3]);
     csw(t0[1], c[1], t0[2], c[2]);
-    if (RESIDENT) {
+    if (fast) {
         const int sp0 = L.sp;
         tv.stack[L.sp * kBlock] = c[3]; L.sp += (t0[3] < inf) ? 1 : 0;   // misses sort last: a slot written for a miss is
         tv.stack[L.sp * kBlock] = c[2]; L.sp += (t0[2] < inf) ? 1 : 0;   // overwritten by the next store or never read
@@ -245,14 +268,14 @@ __device__ __forceinline__ void trav_leaf_step(const TreeView &tv, LaneTrav &L, 
 #ifndef LJ_EXT_POOL
 #define LJ_EXT_POOL 1
 #endif
-constexpr uint32_t kPoolCap = 256;                                      // pairs listed at a time (a wave holds at most 64 x 8)
-constexpr uint32_t kWavePoolBytes = 64 * 8 + 64 * 16 + kPoolCap * 2;    // keys | winners (U, V, S, t) | items
-struct LeafPool { LJ_LDS unsigned long long *keys; LJ_LDS v4f *win; LJ_LDS uint16_t *items; };
+constexpr uint32_t kPoolCap = 256;                                      // pairs listed at a time (a wave holds at most 64 x 16: a held leaf and the one a lane sits on)
+constexpr uint32_t kWavePoolBytes = 64 * 8 + 64 * 16 + kPoolCap * 4;    // keys | winners (U, V, S, t) | items (owner lane | leaf-order primitive index << 6)
+struct LeafPool { LJ_LDS unsigned long long *keys; LJ_LDS v4f *win; LJ_LDS uint32_t *items; };
 
 __device__ __forceinline__ LeafPool leaf_pool_at(uint32_t at) {
     LJ_LDS char *w = (LJ_LDS char *)lj_smem + at + (threadIdx.x >> 6) * kWavePoolBytes;
     LeafPool lp;
-    lp.keys = (LJ_LDS unsigned long long *)w; lp.win = (LJ_LDS v4f *)(w + 64 * 8); lp.items = (LJ_LDS uint16_t *)(w + 64 * 8 + 64 * 16);
+    lp.keys = (LJ_LDS unsigned long long *)w; lp.win = (LJ_LDS v4f *)(w + 64 * 8); lp.items = (LJ_LDS uint32_t *)(w + 64 * 8 + 64 * 16);
     lp.keys[threadIdx.x & 63u] = ~0ull;
     return lp;
 }
@@ -263,8 +286,11 @@ __device__ __forceinline__ float lane_read(int src4, float v) { return __int_as_
 template <bool RESIDENT, bool SPHERES>
 __device__ __forceinline__ uint32_t trav_leaf_pool(const TreeView &tv, const LeafPool &lp, LaneTrav &L, const bool at_leaf, const bool any_hit, uint32_t &n_pairs) {
     const uint32_t lane = threadIdx.x & 63u;
-    const int code = ~L.cur;
-    const int first = code >> 3, count = at_leaf ? (code & 7) + 1 : 0;
+    // this lane's leaves: the one it holds (A) and the one it sits on (B)
+    const int codeA = ~L.held, codeB = ~L.cur;
+    const int firstA = codeA >> 3, cntA = (at_leaf && L.held != 0) ? (codeA & 7) + 1 : 0;
+    const int firstB = codeB >> 3, cntB = (at_leaf && L.cur < 0) ? (codeB & 7) + 1 : 0;
+    const int count = cntA + cntB;
     uint32_t rounds = 0;
     n_pairs = 0;
     for (int j = 0;;) {
@@ -274,7 +300,7 @@ __device__ __forceinline__ uint32_t trav_leaf_pool(const TreeView &tv, const Lea
             const bool has = count > j;
             const unsigned long long b = __ballot(has);
             if (b == 0ull || n_items + 64u > kPoolCap) break;
-            if (has) lp.items[n_items + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u))] = (uint16_t)(lane | ((uint32_t)j << 6));
+            if (has) lp.items[n_items + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u))] = lane | ((uint32_t)(j < cntA ? firstA + j : firstB + (j - cntA)) << 6);
             n_items += (uint32_t)__popcll(b); j++;
         }
         if (n_items == 0u) break;
@@ -283,7 +309,7 @@ __device__ __forceinline__ uint32_t trav_leaf_pool(const TreeView &tv, const Lea
         // ---- test them
         for (uint32_t r = 0; r < n_items; r += 64u, rounds++) {
             const bool act = r + lane < n_items;
-            const uint32_t it = act ? (uint32_t)lp.items[r + lane] : lane;
+            const uint32_t it = act ? lp.items[r + lane] : lane;
             const uint32_t src = it & 63u;
             const int src4 = (int)(src << 2);
             RayF ray;
@@ -292,7 +318,7 @@ __device__ __forceinline__ uint32_t trav_leaf_pool(const TreeView &tv, const Lea
             ray.tnear = lane_read(src4, L.ray.tnear);
             ray.tfar = SPHERES ? lane_read(src4, L.ray.tfar) : 0.0f;
             const float tbest = lane_read(src4, L.best.t);
-            const int pi = __builtin_amdgcn_ds_bpermute(src4, first) + (int)(it >> 6);
+            const int pi = (int)(it >> 6);
             bool hit = false;
             unsigned long long key = 0ull;
             v4f w; w.x = 0.0f; w.y = 0.0f; w.z = 1.0f; w.w = 0.0f;
@@ -336,7 +362,10 @@ __device__ __forceinline__ uint32_t trav_leaf_pool(const TreeView &tv, const Lea
             L.best_S = take ? w.z : L.best_S; L.best.gprim = take ? gprim : L.best.gprim;
             stop = any_hit;
         }
-        L.cur = stop ? kDone : trav_pop<RESIDENT>(tv, L);
+        const bool on_leaf = L.cur < 0;
+        L.held = 0;
+        if (stop) L.cur = kDone;
+        else if (on_leaf) L.cur = trav_pop<RESIDENT>(tv, L);
     }
     return rounds;
 }
@@ -378,7 +407,7 @@ __global__ void __launch_bounds__(kBlock, (RESIDENT && !SPHERES && !STATS) ? LJ_
     // code exists once and the traversal state is rewritten in one region of the loop only
     bool busy = false; int phase = 0; uint32_t path = 0; uint32_t flags = 0; int vis = 0; int start = 0;
     float edx = 0, edy = 0, edz = 0;
-    LaneTrav L; L.cur = kDone; L.sp = 0;
+    LaneTrav L; L.cur = kDone; L.sp = 0; L.held = 0;
     for (;;) {
         if (next == end && !exhausted) {    // open the prefetched chunk and draw the one after it
             const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)pre);
@@ -428,11 +457,14 @@ __global__ void __launch_bounds__(kBlock, (RESIDENT && !SPHERES && !STATS) ? LJ_
         // (lanes that reach a leaf wait here; once only a few lanes are still descending, everybody moves on to the
         // leaf phase and the stragglers resume in the next round)
         for (;;) {
+#if LJ_EXT_HOLD && LJ_EXT_POOL
+            if (busy && L.cur < 0 && L.held == 0 && (LJ_EXT_HOLD_SHADOW || phase != 0)) trav_hold<RESIDENT>(tv, L);
+#endif
             const bool descending = busy && L.cur >= 0 && L.cur != kDone;
             const unsigned long long dm = __ballot(descending);
             if (dm == 0ull) break;
             // only hand over to the leaf phase if some lane actually has a leaf to test (otherwise no progress is made)
-            if ((uint32_t)__popcll(dm) < min_descending && __ballot(busy && L.cur < 0) != 0ull) break;
+            if ((uint32_t)__popcll(dm) < min_descending && __ballot(busy && (L.cur < 0 || L.held != 0)) != 0ull) break;
             if (STATS) { st_nodes++; st_node_lanes += __popcll(dm); }
             if (descending) trav_node_step<RESIDENT>(tv, L);
         }
@@ -440,7 +472,7 @@ __global__ void __launch_bounds__(kBlock, (RESIDENT && !SPHERES && !STATS) ? LJ_
         // ... then the wave tests the primitives of all those leaves together, 64 (ray, primitive) pairs at a time
         {
             uint32_t n_pairs;
-            const uint32_t rounds = trav_leaf_pool<RESIDENT, SPHERES>(tv, lp, L, busy && L.cur < 0, phase == 0, n_pairs);
+            const uint32_t rounds = trav_leaf_pool<RESIDENT, SPHERES>(tv, lp, L, busy && (L.cur < 0 || L.held != 0), phase == 0, n_pairs);
             if (STATS) { st_leaf += rounds; st_leaf_lanes += n_pairs; }
         }
 #else
@@ -671,11 +703,14 @@ __global__ void __launch_bounds__(kBlock) k_trace_rays(DScene sc, const RayIO *r
 #if LJ_EXT_POOL
         for (;;) {
             for (;;) {
+#if LJ_EXT_HOLD && LJ_EXT_POOL
+                if (L.cur < 0 && L.held == 0) trav_hold<false>(tv, L);
+#endif
                 const bool descending = L.cur >= 0 && L.cur != kDone;
                 if (__ballot(descending) == 0ull) break;
                 if (descending) trav_node_step<false>(tv, L);
             }
-            const bool at_leaf = L.cur < 0;
+            const bool at_leaf = L.cur < 0 || L.held != 0;
             if (__ballot(at_leaf) == 0ull) break;
             uint32_t n_pairs;
             (void)trav_leaf_pool<false, true>(tv, lp, L, at_leaf, occ != nullptr, n_pairs);
@@ -779,10 +814,10 @@ ExtendConfig extend_config(int n_nodes, int n_prims, int bvh_depth, int n_sphere
     c.spheres = n_spheres > 0 ? 1 : 0;
     const int need = 3 * (bvh_depth < 1 ? 1 : bvh_depth);
     // LDS image: small scenes (which may become fully resident) get 16 stack levels and up to 40 KiB; for the others 12
-    // levels + 24 KiB (the top ~100 nodes) do as well as 16 + 40 (sponza -1 %, disney_bsdf -4 %; 64 KiB: +30 % — it crowds
-    // out the other workgroups of the CU)
-    // (the leaf pools of k_extend take another 8 KiB per workgroup)
-    int cap = n_prims <= 256 ? 16 : 12, kib = n_prims <= 256 ? (LJ_EXT_POOL ? 32 : 40) : 24;
+    // levels + 20 KiB (the top ~70 nodes): with the 10 KiB of leaf pools a workgroup then takes 30 KiB and five fit a CU (the kernel
+    // needs 92 VGPRs: five waves per SIMD).  tools/lds_sweep.sh, 64 spp: disney_bsdf 28.5 ms at 20-22 KiB against 29.8 at 24 (four
+    // workgroups), sponza flat (63.5 / 63.8); 14 KiB: +2 %; 64 KiB: +30 % — it crowds out the other workgroups of the CU
+    int cap = n_prims <= 256 ? 16 : 12, kib = n_prims <= 256 ? (LJ_EXT_POOL ? 32 : 40) : 20;
     if (const char *e = getenv("LJ_TUNE_EXT_STACK")) cap = atoi(e);
     if (const char *e = getenv("LJ_TUNE_EXT_LDS_KB")) kib = atoi(e);
     c.stack = need < cap ? need : cap;
@@ -793,14 +828,16 @@ ExtendConfig extend_config(int n_nodes, int n_prims, int bvh_depth, int n_sphere
     int max_nodes = (budget - c.lds_prims * 48) / 112;
     if (max_nodes < 0) max_nodes = 0;
     c.lds_nodes = n_nodes < max_nodes ? n_nodes : max_nodes;
+    if (!LJ_EXT_LDS_NODES && c.lds_nodes < n_nodes) c.lds_nodes = 0;
     // whole tree, all primitives and every stack level (+1: the branch-free pushes store one slot ahead) in LDS
     c.resident = (c.lds_nodes == n_nodes && c.lds_prims == n_prims && c.spill_levels == 0 && c.stack + 1 <= 16) ? 1 : 0;
     if (c.resident) c.stack += 1;
     c.smem = (size_t)c.stack * kBlock * 4 + (size_t)c.lds_nodes * 112 + (size_t)c.lds_prims * 48;
     // tuned on MI355X (tools/pool_probe.sh): when the tree is LDS-resident a node step is cheap and waiting for the last
     // descending lane costs little; with nodes in L2 the (pooled) leaf phase starts once fewer than 32 lanes still descend
-    // (sponza / disney_bsdf at 64 spp: 16: 65.2 / 30.6 ms, 24: 64.2 / 30.0, 32: 63.2 / 29.7, 40: 63.3 / 30.3, 48: 67.8 / 31.9)
-    c.refill_min = 8; c.min_descending = (n_nodes <= c.lds_nodes) ? 1 : (LJ_EXT_POOL ? 32 : 24);
+    // (sponza / disney_bsdf at 64 spp: 16: 65.2 / 30.6 ms, 24: 64.2 / 30.0, 32: 63.2 / 29.7, 40: 63.3 / 30.3, 48: 67.8 / 31.9; with held
+    // leaves — a lane that reaches a leaf keeps descending until its second one — 24: 62.6 / 27.8, 32: 61.7 / 27.5, 40: 60.9 / 27.4)
+    c.refill_min = 8; c.min_descending = (n_nodes <= c.lds_nodes) ? 1 : (LJ_EXT_POOL ? (LJ_EXT_HOLD ? 40 : 32) : 24);
     return c;
 }
 int max_stack_depth() { return 40; }  // inner levels; the builder's own cap is 38
