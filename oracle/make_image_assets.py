@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""TEST INFRASTRUCTURE — writes the small PNG / Radiance HDR files the texture-decoder tests read (tests/assets/images/), with its own
-encoders (zlib from the standard library), so that every colour type, bit depth, filter type and the Adam7 interlace occur:
+"""TEST INFRASTRUCTURE — writes the small PNG / Radiance HDR / TGA / BMP files the texture-decoder tests read (tests/assets/images/), with
+its own encoders (zlib from the standard library), so that every PNG colour type, bit depth, filter type and the Adam7 interlace, every
+TGA image type / pixel depth / origin and every BMP header / pixel depth / mask layout the reference's loader accepts occur:
 
     python oracle/make_image_assets.py        # deterministic: same bytes every time
 
@@ -111,6 +112,96 @@ def write_hdr(name, rgbe, rle):
     open(os.path.join(OUT, name), "wb").write(bytes(out))
 
 
+def write_tga(name, px, image_type, bpp, rng, palette=None, pal_bits=24, top_down=False, id_len=0, pal_start=0):
+    """px: (h, w) palette indices / 16-bit words / grey, or (h, w, c) bytes in FILE order (blue first); rows are written in file order
+    (bottom-up unless top_down).  image_type 1 / 2 / 3, +8: run-length packets (raw and repeat packets mixed)."""
+    h, w = px.shape[:2]
+    rle = image_type >= 8
+    pal_len = 0 if palette is None else len(palette)
+    hdr = struct.pack("<BBBHHBHHHHBB", id_len, 1 if palette is not None else 0, image_type, pal_start, pal_len, pal_bits if palette is not None else 0,
+                      0, 0, w, h, bpp, (0x20 if top_down else 0) | (8 if bpp == 32 else 0))
+    out = bytearray(hdr) + bytes(rng.integers(0, 256, id_len).tolist())
+    if palette is not None:
+        out += bytes(pal_start)           # (the reference's loader skips `first entry index` BYTES before the colour map)
+        for e in palette:
+            out += struct.pack("<H", int(e)) if pal_bits in (15, 16) else bytes(int(v) for v in e)
+    nb = (bpp + 7) // 8
+    def pixel(y, x):
+        v = px[y, x]
+        if np.ndim(v) == 0:
+            return int(v).to_bytes(nb, "little")
+        return bytes(int(c) for c in v)
+    rows = range(h) if top_down else range(h - 1, -1, -1)
+    stream = [pixel(y, x) for y in rows for x in range(w)]
+    if not rle:
+        out += b"".join(stream)
+    else:
+        i = 0
+        while i < len(stream):
+            run = 1
+            while i + run < len(stream) and run < 128 and stream[i + run] == stream[i]:
+                run += 1
+            if run >= 2:
+                out += bytes([0x80 | (run - 1)]) + stream[i]
+                i += run
+            else:
+                n = min(int(rng.integers(1, 9)), len(stream) - i)
+                out += bytes([n - 1]) + b"".join(stream[i:i + n])
+                i += n
+    open(os.path.join(OUT, name), "wb").write(bytes(out))
+
+
+def write_bmp(name, rows, bpp, hsz=40, palette=None, masks=None, top_down=False, compress=0, gap=0):
+    """rows: list of h packed scanlines (bytes, unpadded), TOP row first; written bottom-up unless top_down."""
+    h = len(rows)
+    w = rows_width[0]
+    body = b""
+    for r in (rows if top_down else rows[::-1]):
+        body += r + bytes((-len(r)) & 3)
+    pal = b""
+    if palette is not None:
+        for e in palette:
+            pal += bytes([int(e[2]), int(e[1]), int(e[0])]) + (b"" if hsz == 12 else b"\0")
+    if hsz == 12:
+        info = struct.pack("<IHHHH", 12, w, h, 1, bpp)
+    else:
+        info = struct.pack("<IiiHHIIiiII", hsz, w, -h if top_down else h, 1, bpp, compress, len(body), 2835, 2835, 0, 0)
+        if hsz == 56:
+            info += struct.pack("<IIII", 0x11, 0x22, 0x33, 0x44)     # (skipped by the reference's loader, which then reads the masks that follow)
+        if hsz in (40, 56) and compress == 3:
+            info += struct.pack("<III", *masks[:3])
+        if hsz in (108, 124):
+            m = list(masks) if masks is not None else [0, 0, 0, 0]
+            info += struct.pack("<IIII", *m) + struct.pack("<I", 0x73524742) + bytes(48)
+            if hsz == 124:
+                info += bytes(16)
+    offset = 14 + len(info) + len(pal) + gap
+    data = b"BM" + struct.pack("<IHHI", offset + len(body), 0, 0, offset) + info + pal + bytes(gap) + body
+    open(os.path.join(OUT, name), "wb").write(data)
+
+
+rows_width = [0]
+
+
+def bmp_rows(px, bpp):
+    """px: (h, w) integers (indices or packed pixel words) or (h, w, 3) RGB bytes -> packed scanlines"""
+    h, w = px.shape[:2]
+    rows_width[0] = w
+    rows = []
+    for y in range(h):
+        if bpp == 24:
+            rows.append(bytes(int(c) for p_ in px[y] for c in (p_[2], p_[1], p_[0])))
+        elif bpp in (16, 32):
+            rows.append(b"".join(int(v).to_bytes(bpp // 8, "little") for v in px[y]))
+        elif bpp == 8:
+            rows.append(bytes(int(v) for v in px[y]))
+        else:
+            bits = "".join(format(int(v), "0%db" % bpp) for v in px[y])
+            bits += "0" * (-len(bits) % 8)
+            rows.append(bytes(int(bits[i:i + 8], 2) for i in range(0, len(bits), 8)))
+    return rows
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     rng = np.random.default_rng(20261004)
@@ -144,6 +235,48 @@ def main():
     write_hdr("rle.hdr", rgbe, True)
     write_hdr("flat_wide.hdr", rgbe, False)        # w >= 8 without scanline headers: stb's "not run-length encoded" path
     write_hdr("narrow.hdr", rgbe[:, :5].copy(), False)   # w < 8: always flat
+    # ---- TGA: every image type x pixel depth the reference's loader accepts, both origins, run-length packets, an image-id field
+    runs = (xx // 6 + yy // 3)          # long runs for the run-length files
+    bgr = rng.integers(0, 256, (H, W, 3)); bgr[: H // 2] = np.stack([runs * 9 % 256, runs * 5 % 256, runs * 3 % 256], -1)[: H // 2]
+    bgra = np.concatenate([bgr, rng.integers(0, 256, (H, W, 1))], -1)
+    w16 = rng.integers(0, 65536, (H, W)); w16[: H // 2] = (runs * 1057 % 65536)[: H // 2]
+    g8 = rng.integers(0, 256, (H, W)); g8[: H // 2] = (runs * 11 % 256)[: H // 2]
+    write_tga("rgb24.tga", bgr, 2, 24, rng)
+    write_tga("rgb24_top.tga", bgr, 2, 24, rng, top_down=True, id_len=7)
+    write_tga("rgb24_rle.tga", bgr, 10, 24, rng)
+    write_tga("rgba32.tga", bgra, 2, 32, rng)
+    write_tga("rgba32_rle_top.tga", bgra, 10, 32, rng, top_down=True)
+    write_tga("rgb16.tga", w16, 2, 16, rng)
+    write_tga("rgb15_rle.tga", w16 & 0x7fff, 10, 15, rng)
+    write_tga("gray8.tga", g8, 3, 8, rng)
+    write_tga("gray8_rle.tga", g8, 11, 8, rng, top_down=True)
+    write_tga("graya16.tga", w16, 3, 16, rng)                       # 16-bit grey = grey + alpha
+    pal24 = rng.integers(0, 256, (200, 3)); pal32 = rng.integers(0, 256, (64, 4)); pal16 = rng.integers(0, 65536, 300); pal8 = rng.integers(0, 256, (40, 1))
+    write_tga("pal8_24.tga", rng.integers(0, 210, (H, W)), 1, 8, rng, palette=pal24, pal_bits=24)           # (indices >= 200 read entry 0)
+    write_tga("pal8_32_rle.tga", runs % 64, 9, 8, rng, palette=pal32, pal_bits=32, top_down=True)
+    write_tga("pal16_16.tga", rng.integers(0, 300, (H, W)), 1, 16, rng, palette=pal16, pal_bits=16)
+    write_tga("pal8_15_start.tga", rng.integers(0, 30, (H, W)), 1, 8, rng, palette=pal16[:30] & 0x7fff, pal_bits=15, pal_start=5)
+    write_tga("pal8_8.tga", rng.integers(0, 40, (H, W)), 1, 8, rng, palette=pal8, pal_bits=8)
+    # ---- BMP: header variants x pixel depths x mask layouts, both row orders, a gap before the pixel data
+    rgb = bgr[..., ::-1]
+    write_bmp("rgb24.bmp", bmp_rows(rgb, 24), 24)
+    write_bmp("rgb24_top.bmp", bmp_rows(rgb, 24), 24, top_down=True)
+    write_bmp("rgb24_core.bmp", bmp_rows(rgb, 24), 24, hsz=12)
+    write_bmp("rgb24_v5.bmp", bmp_rows(rgb, 24), 24, hsz=124)
+    w32 = rng.integers(0, 1 << 32, (H, W), dtype=np.uint64)
+    write_bmp("rgb32.bmp", bmp_rows(w32, 32), 32)                                                            # default masks: B, G, R, A bytes
+    write_bmp("rgb32_v4_alpha.bmp", bmp_rows(w32, 32), 32, hsz=108, masks=(0xff0000, 0xff00, 0xff, 0xff000000), compress=3)
+    write_bmp("rgb32_fields.bmp", bmp_rows(w32, 32), 32, masks=(0x0ff00000, 0x0003f000, 0x00000ff0), compress=3)
+    write_bmp("rgb32_fields_v3.bmp", bmp_rows(w32, 32), 32, hsz=56, masks=(0x000000ff, 0x0000ff00, 0x00ff0000), compress=3)
+    write_bmp("rgb16_555.bmp", bmp_rows(w16, 16), 16)
+    write_bmp("rgb16_565.bmp", bmp_rows(w16, 16), 16, masks=(0xf800, 0x07e0, 0x001f), compress=3)
+    write_bmp("rgb16_v4_4444.bmp", bmp_rows(w16, 16), 16, hsz=108, masks=(0x0f00, 0x00f0, 0x000f, 0xf000), compress=3)
+    write_bmp("rgb16_odd_fields.bmp", bmp_rows(w16, 16), 16, masks=(0xe000, 0x1800, 0x00fe), compress=3)      # 3-, 2- and 7-bit channels
+    write_bmp("pal8.bmp", bmp_rows(rng.integers(0, 200, (H, W)), 8), 8, palette=rng.integers(0, 256, (200, 3)))
+    write_bmp("pal8_top.bmp", bmp_rows(rng.integers(0, 256, (H, W)), 8), 8, palette=rng.integers(0, 256, (256, 3)), top_down=True)
+    write_bmp("pal4_gap.bmp", bmp_rows(rng.integers(0, 16, (H, W)), 4), 4, palette=rng.integers(0, 256, (16, 3)), gap=6)
+    write_bmp("pal1.bmp", bmp_rows((xx * 3 + yy * 5) // 4 % 2, 1), 1, palette=rng.integers(0, 256, (2, 3)))
+    write_bmp("pal4_v5.bmp", bmp_rows(rng.integers(0, 9, (H, W)), 4), 4, hsz=124, palette=rng.integers(0, 256, (9, 3)))
     print("wrote", len(os.listdir(OUT)), "files to", OUT)
 
 

@@ -276,13 +276,17 @@ def _fnv1a64(a):
     return "%016x" % h
 
 
-def test_png_and_hdr_decoders_match_the_reference_loaders():
-    """imread3 / imread1 hand .png and .hdr files to stb_image (image.cpp:28-133).  tests/assets/images/ holds small files of every PNG
-    colour type / bit depth / filter type, Adam7, palettes with tRNS, and Radiance HDR in its three encodings (written by
-    oracle/make_image_assets.py); tests/golden/image_decode.json is what the reference's own loaders return for them
-    (oracle/decode_with_reference.cpp).  Our decoders (png_decode.cpp) must return the same floats, bit for bit."""
+def test_png_hdr_tga_bmp_decoders_match_the_reference_loaders():
+    """imread3 / imread1 hand .png, .hdr, .tga and .bmp files to stb_image (image.cpp:28-133).  tests/assets/images/ holds small files of
+    every PNG colour type / bit depth / filter type, Adam7, palettes with tRNS, Radiance HDR in its three encodings, every TGA image type
+    (colour-mapped, true colour, grey; raw and run-length) x pixel / palette depth x origin, and BMP files of every header size, palette
+    depth, 16 / 24 / 32-bit pixel layout and bit-field mask the reference's loader accepts (written by oracle/make_image_assets.py);
+    tests/golden/image_decode.json is what the reference's own loaders return for them (oracle/decode_with_reference.cpp).  Our decoders
+    (png_decode.cpp, tga_bmp_decode.cpp) must return the same floats, bit for bit."""
     g = golden("image_decode")["files"]
-    assert len(g) >= 23 and {"gray1.png", "rgb16_interlaced.png", "pal4.png", "graya16.png", "rle.hdr", "flat_wide.hdr", "narrow.hdr"} <= set(g)
+    assert len(g) >= 55 and {"gray1.png", "rgb16_interlaced.png", "pal4.png", "graya16.png", "rle.hdr", "flat_wide.hdr", "narrow.hdr",
+                             "rgb24_rle.tga", "rgb15_rle.tga", "graya16.tga", "pal16_16.tga", "pal8_15_start.tga", "gray8_rle.tga",
+                             "rgb24_core.bmp", "rgb32_fields_v3.bmp", "rgb16_odd_fields.bmp", "pal1.bmp", "pal4_gap.bmp", "rgb16_v4_4444.bmp"} <= set(g)
     for name, e in sorted(g.items()):
         for ch, key in ((3, "imread3"), (1, "imread1")):
             img = lj.read_image(os.path.join(ROOT, "tests", "assets", "images", name), ch)
@@ -293,7 +297,9 @@ def test_png_and_hdr_decoders_match_the_reference_loaders():
 
 
 def test_unsupported_and_broken_images_fail_loudly(tmp_path):
-    for name, payload in (("x.tga", b"\0" * 64), ("x.png", b"\x89PNG\r\n\x1a\n" + b"\0" * 40), ("x.hdr", b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 2 +X 9\n\2\2\0")):
+    bmp_rle = b"BM" + (54 + 8).to_bytes(4, "little") + b"\0" * 4 + (54).to_bytes(4, "little") + (40).to_bytes(4, "little") + (2).to_bytes(4, "little") * 2 + b"\1\0\x08\0" + (1).to_bytes(4, "little") + b"\0" * 28
+    for name, payload in (("x.tga", b"\0" * 64), ("x.gif", b"GIF89a" + b"\0" * 32), ("x.bmp", bmp_rle), ("y.bmp", b"BM" + b"\0" * 60),
+                          ("x.png", b"\x89PNG\r\n\x1a\n" + b"\0" * 40), ("x.hdr", b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 2 +X 9\n\2\2\0")):
         p = tmp_path / name
         p.write_bytes(payload)
         with pytest.raises(lj.LajollaError) as e:
