@@ -48,8 +48,10 @@ RenderPlan make_plan(const lj_scene *sc, const LjRenderArgs *a) {
     if (p.spp <= 0) throw LjError(LJ_ERR_INVALID_ARG, "samples per pixel must be positive");
     p.seed = (a && a->seed) ? a->seed : 0x853c49e6748fea9bULL;
     p.max_depth = (a && a->max_depth != INT32_MIN) ? a->max_depth : sc->flat.max_depth;
-    p.pool = (a && a->pool_paths) ? a->pool_paths : (1u << 25);  // 32 M paths in flight = 4 GiB of queue records, 8 M per lane:
-    // long per-wave slices keep the extend kernel's lanes refilled (a wave's drain phase is amortised over ~2 k paths)
+    // 128 M paths in flight = 16 GiB of queue records (of the 288 GB a MI355X has; allocated only as far as a pass has samples): long
+    // per-wave slices keep the extend kernel's lanes refilled and every launch's drain phase is amortised over more paths
+    // (tools/pool_big.sh, sponza 1024 spp: 2^25 828 ms, 2^26 811, 2^27 794, 2^28 793; disney_bsdf 256 spp: 97.3 / 93.4 / 91.8 / 91.5)
+    p.pool = (a && a->pool_paths) ? a->pool_paths : (1u << 27);
     p.pool = std::max<uint32_t>(p.pool, 4096);
     if (a && a->rng_mode != LJ_RNG_SAMPLE) throw LjError(LJ_ERR_UNSUPPORTED, "only LJ_RNG_SAMPLE exists on the device (a per-tile sequential stream cannot be parallelised, SURVEY §0.2)");
     int rank = a ? a->rank : 0, world = (a && a->world_size > 0) ? a->world_size : 1;
@@ -164,8 +166,12 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
         HIP_CHECK(hipEventRecord(ctx->ev_begin, stream));
         int per_cu = ljd::mega_blocks_per_cu(sc->scfg);
         if (const char *e = getenv("LJ_TUNE_MEGA_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(e));
-        uint32_t grab = 1024;   // camera samples a wave takes off the counter at a time: a multiple of 64 so that a wave's lanes share pixels
-        if (const char *e = getenv("LJ_TUNE_MEGA_GRAB")) grab = (uint32_t)std::max(64, atoi(e)) & ~63u;
+        // camera samples a wave takes off the counter at a time: a multiple of 64 so that a wave's lanes share pixels; 1024 for a full
+        // frame, less when the pass is small (one rank's share of N: tools/shard_time.py) so that every wave still draws ~8 times and
+        // the grid ends together — a 1/8 share of the bench frame took 2.50 ms with 1.6 draws of 1024 per wave (ideal 1.65)
+        uint32_t grab_max = 1024;
+        bool grab_fixed = false;
+        if (const char *e = getenv("LJ_TUNE_MEGA_GRAB")) { grab_max = (uint32_t)std::max(64, atoi(e)) & ~63u; grab_fixed = true; }
         double mega_ms = 0;
         unsigned long long hstats[5] = {};
         for (uint64_t p0 = 0; p0 < n_pix; p0 += pix_per_pass) {
@@ -175,6 +181,13 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
             pass.pixel_list = (const uint32_t *)ctx->pixel_list.p + p0; pass.n_pixels = (uint32_t)np; pass.spp = (uint32_t)plan.spp;
             pass.seed = plan.seed; pass.sample_rgb = (float *)ctx->sample_rgb.p;
             HIP_CHECK(hipMemsetAsync(ctx->mega_state.p, 0, 64, stream));
+            uint32_t grab = grab_max;
+            if (!grab_fixed) {
+                uint64_t draws = 8;
+                if (const char *e = getenv("LJ_TUNE_MEGA_DRAWS")) draws = (uint64_t)std::max(1, atoi(e));
+                const uint64_t waves = (uint64_t)ctx->n_cus * per_cu * 4, per_draw = total / (waves * draws);
+                grab = (uint32_t)std::min<uint64_t>(grab_max, std::max<uint64_t>(64, per_draw & ~(uint64_t)63));
+            }
             // persistent grid: as many workgroups as stay resident, but no more waves than there are `grab`-sized pieces of work
             const uint64_t pieces = (total + grab - 1) / grab;
             const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)ctx->n_cus * per_cu, (pieces + 3) / 4));
