@@ -1,5 +1,6 @@
 // OpenEXR input for the texture front end (image.cpp:54-73,109-129 in the reference, which delegates to tinyexr's
-// LoadEXR): single-part scan-line files with HALF / FLOAT / UINT channels, compression NONE, ZIPS, ZIP or PIZ —
+// LoadEXR): single-part scan-line and tiled files (level 0 of a mip- / rip-mapped one, as LoadEXR assembles it) with HALF / FLOAT /
+// UINT channels, compression NONE, ZIPS, ZIP or PIZ —
 // written from the OpenEXR file-format and PIZ documentation (Huffman coding + 2-D Haar wavelet + value LUT), no
 // third-party code.  Output: R, G, B as float, row-major, y = 0 at the top; a file with a single channel is replicated
 // to all three (tinyexr's behaviour for LoadEXR).  HALF -> float is exact, so texels are bit-identical to what the
@@ -237,9 +238,11 @@ HostImage decode_exr_rgb(const std::vector<uint8_t> &file, const std::string &na
     Reader r{file.data(), file.data() + file.size(), name};
     if (r.u32() != 20000630u) throw LjError(LJ_ERR_PARSE, "not an OpenEXR file: " + name);
     const uint32_t version = r.u32();
-    if ((version & 0xff) != 2 || (version & 0x1a00)) throw LjError(LJ_ERR_UNSUPPORTED, "only single-part scan-line OpenEXR files are read (no tiles, deep data or multi-part): " + name);
+    if ((version & 0xff) != 2 || (version & 0x1800)) throw LjError(LJ_ERR_UNSUPPORTED, "only single-part OpenEXR images are read (no deep data or multi-part files): " + name);
+    const bool tiled = (version & 0x200) != 0;
     std::vector<Channel> chans;
     int compression = -1, x0 = 0, y0 = 0, x1 = -1, y1 = -1, line_order = 0;
+    uint32_t tile_w = 0, tile_h = 0;
     for (;;) {
         const std::string attr = r.str();
         if (attr.empty()) break;
@@ -262,6 +265,7 @@ HostImage decode_exr_rgb(const std::vector<uint8_t> &file, const std::string &na
         } else if (attr == "compression") compression = v.u8();
         else if (attr == "dataWindow") { x0 = v.i32(); y0 = v.i32(); x1 = v.i32(); y1 = v.i32(); }
         else if (attr == "lineOrder") line_order = v.u8();
+        else if (attr == "tiles") { tile_w = v.u32(); tile_h = v.u32(); (void)v.u8(); }   // (level mode: only level 0 is read, as LoadEXR does)
     }
     (void)line_order;   // blocks carry their own y coordinate
     if (chans.empty() || x1 < x0 || y1 < y0) throw LjError(LJ_ERR_PARSE, "EXR header lacks channels or a data window: " + name);
@@ -280,10 +284,55 @@ HostImage decode_exr_rgb(const std::vector<uint8_t> &file, const std::string &na
     for (size_t i = 0; i < chans.size(); i++) { if (chans[i].name == "R") src[0] = (int)i; else if (chans[i].name == "G") src[1] = (int)i; else if (chans[i].name == "B") src[2] = (int)i; }
     if (chans.size() == 1) src[0] = src[1] = src[2] = 0;
     if (src[0] < 0 || src[1] < 0 || src[2] < 0) throw LjError(LJ_ERR_UNSUPPORTED, "EXR file has neither R, G, B channels nor a single channel: " + name);
-    std::vector<size_t> chan_off(chans.size());
-    { size_t o = 0; for (size_t i = 0; i < chans.size(); i++) { chan_off[i] = o; o += (size_t)w * chans[i].words * 2; } }
     HostImage img; img.width = w; img.height = h; img.channels = 3;
     img.data.assign((size_t)w * h * 3, 0.0f);
+    // `n` texels of every channel, one channel after the other (a scan line, or a tile's part of one) -> R, G, B at dst
+    auto unpack_line = [&](const uint8_t *line, int n, float *dst) {
+        size_t o = 0;
+        std::vector<size_t> off(chans.size());
+        for (size_t i = 0; i < chans.size(); i++) { off[i] = o; o += (size_t)n * chans[i].words * 2; }
+        for (int k = 0; k < 3; k++) {
+            const Channel &c = chans[src[k]];
+            const uint8_t *s = line + off[src[k]];
+            for (int x = 0; x < n; x++) {
+                float v;
+                if (c.type == 1) { uint16_t hv; memcpy(&hv, s + 2 * x, 2); v = half_to_float(hv); }
+                else if (c.type == 2) memcpy(&v, s + 4 * x, 4);
+                else { uint32_t u; memcpy(&u, s + 4 * x, 4); v = (float)u; }
+                dst[3 * x + k] = v;
+            }
+        }
+    };
+    if (tiled) {
+        // Tiles of level (0, 0) — what LoadEXR assembles; their offsets lead the table whatever the level mode.  A tile at the right /
+        // lower edge holds only its part inside the data window; each tile is compressed on its own, lines and channels laid out as
+        // in a scan-line block.
+        if (tile_w == 0 || tile_h == 0 || tile_w > (1u << 20) || tile_h > (1u << 20)) throw LjError(LJ_ERR_PARSE, "tiled EXR without a tile description: " + name);
+        const int ntx = (int)((w + tile_w - 1) / tile_w), nty = (int)((h + tile_h - 1) / tile_h);
+        std::vector<uint64_t> offsets((size_t)ntx * nty);
+        for (auto &o : offsets) o = r.u64();
+        std::vector<uint8_t> raw;
+        for (uint64_t at : offsets) {
+            if (at + 20 > file.size()) throw LjError(LJ_ERR_PARSE, "EXR tile offset outside the file: " + name);
+            Reader br{file.data() + at, file.data() + file.size(), name};
+            const int tx = br.i32(), ty = br.i32(), lx = br.i32(), ly = br.i32();
+            const int32_t size = br.i32();
+            if (lx != 0 || ly != 0 || tx < 0 || ty < 0 || tx >= ntx || ty >= nty || size < 0) throw LjError(LJ_ERR_PARSE, "EXR tile header: " + name);
+            br.need((size_t)size);
+            const int px = tx * (int)tile_w, py = ty * (int)tile_h, tw = std::min((int)tile_w, w - px), th = std::min((int)tile_h, h - py);
+            size_t tline = 0;
+            for (const Channel &c : chans) tline += (size_t)tw * c.words * 2;
+            const size_t expect = tline * th;
+            const uint8_t *data = br.p;
+            if ((size_t)size == expect) raw.assign(data, data + size);
+            else if (compression == 4) piz_decode(data, (size_t)size, raw, tw, th, chans, name);
+            else if (compression == 2 || compression == 3) zip_decode(data, (size_t)size, raw, expect, name);
+            else throw LjError(LJ_ERR_PARSE, "EXR tile size: " + name);
+            if (raw.size() != expect) throw LjError(LJ_ERR_PARSE, "EXR tile decodes to the wrong size: " + name);
+            for (int y = 0; y < th; y++) unpack_line(raw.data() + (size_t)y * tline, tw, img.data.data() + ((size_t)(py + y) * w + px) * 3);
+        }
+        return img;
+    }
     const int n_blocks = (h + block_lines - 1) / block_lines;
     std::vector<uint64_t> offsets(n_blocks);
     for (auto &o : offsets) o = r.u64();
@@ -303,21 +352,7 @@ HostImage decode_exr_rgb(const std::vector<uint8_t> &file, const std::string &na
         else if (compression == 2 || compression == 3) zip_decode(data, (size_t)size, raw, expect, name);
         else throw LjError(LJ_ERR_PARSE, "EXR block size: " + name);
         if (raw.size() != expect) throw LjError(LJ_ERR_PARSE, "EXR block decodes to the wrong size: " + name);
-        for (int y = 0; y < lines; y++) {
-            const uint8_t *line = raw.data() + (size_t)y * line_bytes;
-            float *dst = img.data.data() + (size_t)(by + y) * w * 3;
-            for (int k = 0; k < 3; k++) {
-                const Channel &c = chans[src[k]];
-                const uint8_t *s = line + chan_off[src[k]];
-                for (int x = 0; x < w; x++) {
-                    float v;
-                    if (c.type == 1) { uint16_t hv; memcpy(&hv, s + 2 * x, 2); v = half_to_float(hv); }
-                    else if (c.type == 2) memcpy(&v, s + 4 * x, 4);
-                    else { uint32_t u; memcpy(&u, s + 4 * x, 4); v = (float)u; }
-                    dst[3 * x + k] = v;
-                }
-            }
-        }
+        for (int y = 0; y < lines; y++) unpack_line(raw.data() + (size_t)y * line_bytes, w, img.data.data() + (size_t)(by + y) * w * 3);
     }
     return img;
 }

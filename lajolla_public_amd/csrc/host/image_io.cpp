@@ -7,7 +7,7 @@
 //                 (float) pow(v / 255.0f, 2.2f)  (stb_image.h:1553,1849) — what the reference's ImageTextures hold.
 //   .png / .hdr   PNG (all colour types and bit depths, Adam7) and Radiance RGBE (png_decode.cpp), with stb's conventions
 //   .tga / .bmp   Truevision TGA and Windows BMP (tga_bmp_decode.cpp), likewise
-//   .exr          single-part scan-line OpenEXR, HALF / FLOAT / UINT channels, NONE / ZIPS / ZIP / PIZ (exr_decode.cpp);
+//   .exr          single-part scan-line or tiled OpenEXR, HALF / FLOAT / UINT channels, NONE / ZIPS / ZIP / PIZ (exr_decode.cpp);
 //                 three channels = R, G, B; one channel = their mean (image.cpp:70-72)
 // Other formats fail loudly.
 #include "host_scene.h"
@@ -84,8 +84,10 @@ HostImage read_image(const std::string &filename, int channels) {
         if (channels != 1) return rgb;
         HostImage g; g.width = rgb.width; g.height = rgb.height; g.channels = 1;
         g.data.resize((size_t)rgb.width * rgb.height);
-        for (size_t i = 0; i < g.data.size(); i++)   // image.cpp:70-72, in the reference's double arithmetic
-            g.data[i] = (float)(((double)rgb.data[3 * i] + (double)rgb.data[3 * i + 1] + (double)rgb.data[3 * i + 2]) / 3);
+        for (size_t i = 0; i < g.data.size(); i++) {   // image.cpp:70-72: the mean of tinyexr's three FLOATS, formed in float arithmetic
+            const float sum = (rgb.data[3 * i] + rgb.data[3 * i + 1]) + rgb.data[3 * i + 2];
+            g.data[i] = sum / 3;
+        }
         return g;
     }
     if (ext == ".jpg" || ext == ".jpeg") {

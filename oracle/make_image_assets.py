@@ -202,6 +202,59 @@ def bmp_rows(px, bpp):
     return rows
 
 
+def exr_zip(raw):
+    """OpenEXR ZIP block: bytes split into even / odd halves, delta-coded, deflated (stored raw when that is not smaller)"""
+    n = len(raw)
+    t = bytearray(raw[0::2] + raw[1::2])
+    prev = t[0]
+    for i in range(1, n):
+        cur = t[i]
+        t[i] = (cur - prev + 128) & 0xff
+        prev = cur
+    z = zlib.compress(bytes(t), 6)
+    return z if len(z) < n else raw
+
+
+def write_exr_tiled(name, chans, tile, compression, mipmap=False):
+    """chans: list of (name, 'half' | 'float', (h, w) array), written in alphabetical order; tile = (xs, ys); compression 0 (none) or 3
+    (zip: one block per tile).  mipmap: the lower levels are present too (box-filtered), as a MIPMAP_LEVELS / ROUND_DOWN file holds them."""
+    chans = sorted(chans, key=lambda c: c[0])
+    h, w = chans[0][2].shape
+    xs, ys = tile
+    def attr(n, t, v):
+        return n.encode() + b"\0" + t.encode() + b"\0" + struct.pack("<I", len(v)) + v
+    chlist = b"".join(n.encode() + b"\0" + struct.pack("<iBBBBii", 1 if t == "half" else 2, 0, 0, 0, 0, 1, 1) for n, t, _ in chans) + b"\0"
+    hdr = struct.pack("<II", 20000630, 2 | 0x200)
+    hdr += attr("channels", "chlist", chlist) + attr("compression", "compression", bytes([compression]))
+    hdr += attr("dataWindow", "box2i", struct.pack("<iiii", 0, 0, w - 1, h - 1)) + attr("displayWindow", "box2i", struct.pack("<iiii", 0, 0, w - 1, h - 1))
+    hdr += attr("lineOrder", "lineOrder", b"\0") + attr("pixelAspectRatio", "float", struct.pack("<f", 1.0))
+    hdr += attr("screenWindowCenter", "v2f", struct.pack("<ff", 0, 0)) + attr("screenWindowWidth", "float", struct.pack("<f", 1.0))
+    hdr += attr("tiles", "tiledesc", struct.pack("<IIB", xs, ys, 1 if mipmap else 0)) + b"\0"
+    levels = [[c[2] for c in chans]]
+    if mipmap:
+        lw, lh = w, h
+        while max(lw, lh) > 1:
+            lw, lh = max(1, lw // 2), max(1, lh // 2)
+            levels.append([np.ascontiguousarray(a[: lh * (a.shape[0] // lh) : a.shape[0] // lh, : lw * (a.shape[1] // lw) : a.shape[1] // lw][:lh, :lw]) for a in levels[0]])
+    chunks = []
+    for l, arrs in enumerate(levels):
+        lh, lw = arrs[0].shape
+        for ty in range((lh + ys - 1) // ys):
+            for tx in range((lw + xs - 1) // xs):
+                raw = b""
+                for y in range(ty * ys, min(lh, (ty + 1) * ys)):
+                    for (n, t, _), a in zip(chans, arrs):
+                        raw += a[y, tx * xs:min(lw, (tx + 1) * xs)].astype("<f2" if t == "half" else "<f4").tobytes()
+                data = exr_zip(raw) if compression == 3 else raw
+                chunks.append(struct.pack("<iiiii", tx, ty, l, l, len(data)) + data)
+    pos = len(hdr) + 8 * len(chunks)
+    table = b""
+    for c in chunks:
+        table += struct.pack("<Q", pos)
+        pos += len(c)
+    open(os.path.join(OUT, name), "wb").write(hdr + table + b"".join(chunks))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     rng = np.random.default_rng(20261004)
@@ -277,6 +330,12 @@ def main():
     write_bmp("pal4_gap.bmp", bmp_rows(rng.integers(0, 16, (H, W)), 4), 4, palette=rng.integers(0, 256, (16, 3)), gap=6)
     write_bmp("pal1.bmp", bmp_rows((xx * 3 + yy * 5) // 4 % 2, 1), 1, palette=rng.integers(0, 256, (2, 3)))
     write_bmp("pal4_v5.bmp", bmp_rows(rng.integers(0, 9, (H, W)), 4), 4, hsz=124, palette=rng.integers(0, 256, (9, 3)))
+    # ---- tiled OpenEXR (single part): edge tiles, HALF and FLOAT channels, an alpha channel to skip, one grey channel, a mip-mapped file
+    fr, fg, fb = (rng.random((H, W)) * 4 - 1 for _ in range(3))
+    write_exr_tiled("tiled_half_none.exr", [("R", "half", fr), ("G", "half", fg), ("B", "half", fb)], (16, 8), 0)
+    write_exr_tiled("tiled_float_zip.exr", [("R", "float", fr), ("G", "float", fg), ("B", "float", fb), ("A", "half", fr * 0 + 1)], (10, 10), 3)
+    write_exr_tiled("tiled_grey_zip.exr", [("Y", "half", np.round(fg * 8) / 8)], (64, 64), 3)
+    write_exr_tiled("tiled_mipmap_zip.exr", [("R", "half", fb), ("G", "float", fr), ("B", "half", fg)], (8, 8), 3, mipmap=True)
     print("wrote", len(os.listdir(OUT)), "files to", OUT)
 
 
