@@ -203,7 +203,7 @@ typedef struct LjRenderArgs {
     int32_t rank, world_size; /* render only the 16x16 tiles t = ty*ntx+tx with t % world_size == rank (render.cpp:75-88);
                                  other pixels are written as 0 so a sum over ranks is the full image */
     int32_t crop_x0, crop_y0, crop_x1, crop_y1; /* all 0: full frame; else only pixels in [x0,x1)x[y0,y1) */
-    uint32_t pool_paths; /* in-flight path pool size; 0: default */
+    uint32_t pool_paths; /* paths in flight (128 bytes of queue records each, allocated as far as a pass has samples); 0: default = 128 M */
     uint32_t flags;
     uint64_t seed;       /* 0: 0x853c49e6748fea9b (pcg.h:33) */
 } LjRenderArgs;
