@@ -546,10 +546,15 @@ __device__ __forceinline__ uint32_t shade_compact_segment(const DScene &sc, cons
 #define LJ_LAMBERT_OCC 4
 #endif
 #ifndef LJ_SHADE_OCC
-#define LJ_SHADE_OCC 3   // the feature sets beyond Lambert-only need ~150 VGPRs: at 4 waves they spill (sponza -2 %, matpreview -3 % at 3)
+#define LJ_SHADE_OCC 3   // the feature sets beyond Lambert-only need 140 - 165 VGPRs: at 4 waves they spill (matpreview -3 % at 3)
 #endif
+#ifndef LJ_SHADE_OCC_LARGE
+#define LJ_SHADE_OCC_LARGE 4   // ... but the two that run alone on the GPU beside a large tree's extend launches (one lane) gain from the fourth wave:
+#endif                         // sponza 256 spp 200.0 -> 196.8 ms (shade alone -6.5 %), disney_bsdf 256 spp 91.6 -> 89.9 (tools/variant_ab.sh)
 template <class Ft> struct ShadeOccupancy { static constexpr int waves = LJ_SHADE_OCC; };
 template <> struct ShadeOccupancy<FeatLambert> { static constexpr int waves = LJ_LAMBERT_OCC; };
+template <> struct ShadeOccupancy<FeatLambertTex> { static constexpr int waves = LJ_SHADE_OCC_LARGE; };
+template <> struct ShadeOccupancy<FeatDisney> { static constexpr int waves = LJ_SHADE_OCC_LARGE; };
 
 template <class Ft, int STAGE>
 __global__ void __launch_bounds__(kBlock, ShadeOccupancy<Ft>::waves) k_shade(DScene sc, DPass pass, DQueue q, DBlockState *blocks, uint32_t seg, ShadeStage stg, uint32_t *work, uint32_t *chunk_list, uint32_t parity, uint32_t extend_waves) {

@@ -1,5 +1,5 @@
-// Truevision TGA and Windows BMP texture decoders of the front end.  The reference's imread3 / imread1 (image.cpp:28-133) hand .tga and
-// .bmp files to stb_image's float loader; these decoders are written from the file formats and reproduce what that loader returns, texel
+// Truevision TGA, Windows BMP and Photoshop PSD texture decoders of the front end.  The reference's imread3 / imread1 (image.cpp:28-133) hand
+// .tga, .bmp and .psd files to stb_image's float loader; these decoders are written from the file formats and reproduce what that loader returns, texel
 // for texel (pinned by tests/golden/image_decode.json, which the reference's own imread3 / imread1 produced for tests/assets/images/*):
 //   TGA   colour-mapped (types 1 / 9), true colour (2 / 10) and grey (3 / 11), raw or run-length packets; 8 / 15 / 16 / 24 / 32 bits per
 //         pixel or palette entry (15 / 16: five bits per channel, x * 255 / 31, the top bit ignored); rows bottom-up unless bit 5 of the
@@ -7,6 +7,8 @@
 //   BMP   core (12-byte), info (40 / 56), V4 (108) and V5 (124) headers; 1 / 4 / 8-bit palettes, 16 / 24 / 32-bit pixels with the default
 //         or BI_BITFIELDS masks (a channel of n < 8 bits is widened by bit replication); bottom-up unless the height is negative;
 //         run-length compressed files are refused (the reference's loader refuses them too)
+//   PSD   version 1, RGB mode, 8 or 16 bits per channel (the high byte is kept), raw or PackBits planes; the composite image only; with an
+//         alpha plane the colours are un-matted from white where 0 < alpha < 255, in float, as the reference's loader does
 // then the conversion every LDR file goes through: luma (77 R + 150 G + 29 B) >> 8 for one channel, and (float) pow(v / 255.0f, 2.2f).
 #include "host_scene.h"
 #include <cmath>
@@ -209,6 +211,60 @@ HostImage read_bmp(const std::vector<uint8_t> &file, const std::string &name, in
         for (int y = 0; y < (h >> 1); y++)
             for (size_t k = 0; k < (size_t)w * 3; k++) std::swap(px[(size_t)y * w * 3 + k], px[(size_t)(h - 1 - y) * w * 3 + k]);
     return finish_ldr(px, w, h, 3, channels);
+}
+
+HostImage read_psd(const std::vector<uint8_t> &file, const std::string &name, int channels) {
+    Reader r{file, name};
+    auto be16 = [&]() { const uint32_t a = r.u8(); return (a << 8) | r.u8(); };
+    auto be32 = [&]() { const uint32_t a = be16(); return (a << 16) | be16(); };
+    if (be32() != 0x38425053u) throw LjError(LJ_ERR_PARSE, "not a PSD file: " + name);
+    if (be16() != 1) throw LjError(LJ_ERR_UNSUPPORTED, "PSD version is not 1: " + name);
+    r.skip(6);
+    const int n_ch = (int)be16();
+    if (n_ch > 16) throw LjError(LJ_ERR_UNSUPPORTED, "PSD with more than 16 channels: " + name);
+    const long long h = (int32_t)be32(), w = (int32_t)be32();
+    if (w <= 0 || h <= 0 || w > (1 << 24) || h > (1 << 24)) throw LjError(LJ_ERR_PARSE, "corrupt PSD (size): " + name);
+    const int depth = (int)be16();
+    if (depth != 8 && depth != 16) throw LjError(LJ_ERR_UNSUPPORTED, "PSD bit depth is not 8 or 16: " + name);
+    if (be16() != 3) throw LjError(LJ_ERR_UNSUPPORTED, "PSD is not in RGB colour mode: " + name);
+    r.skip(be32()); r.skip(be32()); r.skip(be32());   // mode data, image resources, layers
+    const int compression = (int)be16();
+    if (compression > 1) throw LjError(LJ_ERR_UNSUPPORTED, "PSD compression other than raw / PackBits: " + name);
+    const size_t n = (size_t)w * (size_t)h;
+    std::vector<uint8_t> px(n * 4);
+    if (compression) r.skip(h * n_ch * 2);   // the per-row byte counts: the planes are decoded as one run of w * h samples each
+    for (int c = 0; c < 4; c++) {
+        if (c >= n_ch) { for (size_t i = 0; i < n; i++) px[4 * i + c] = c == 3 ? 255 : 0; continue; }
+        if (!compression) {
+            for (size_t i = 0; i < n; i++) px[4 * i + c] = depth == 16 ? (uint8_t)(be16() >> 8) : r.u8();
+            continue;
+        }
+        size_t count = 0;
+        while (count < n) {
+            int len = r.u8();
+            if (len == 128) { if (r.p >= file.size()) throw LjError(LJ_ERR_PARSE, "truncated PSD plane: " + name); continue; }
+            if (len < 128) {
+                len++;
+                if ((size_t)len > n - count) throw LjError(LJ_ERR_PARSE, "corrupt PSD run: " + name);
+                for (int k = 0; k < len; k++) px[4 * (count++) + c] = r.u8();
+            } else {
+                len = 257 - len;
+                if ((size_t)len > n - count) throw LjError(LJ_ERR_PARSE, "corrupt PSD run: " + name);
+                const uint8_t v = r.u8();
+                for (int k = 0; k < len; k++) px[4 * (count++) + c] = v;
+            }
+            if (r.p >= file.size() && count < n) throw LjError(LJ_ERR_PARSE, "truncated PSD plane: " + name);
+        }
+    }
+    if (n_ch >= 4)
+        for (size_t i = 0; i < n; i++) {
+            uint8_t *q = &px[4 * i];
+            if (q[3] != 0 && q[3] != 255) {   // colours stored matted against white: c = (c - 255 (1 - a)) / a, in the reference loader's float steps
+                const float a = q[3] / 255.0f, ra = 1.0f / a, inv_a = 255.0f * (1 - ra);
+                for (int c = 0; c < 3; c++) q[c] = (unsigned char)(q[c] * ra + inv_a);
+            }
+        }
+    return finish_ldr(px, (int)w, (int)h, 4, channels);
 }
 
 } // namespace lj

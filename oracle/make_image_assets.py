@@ -255,6 +255,36 @@ def write_exr_tiled(name, chans, tile, compression, mipmap=False):
     open(os.path.join(OUT, name), "wb").write(hdr + table + b"".join(chunks))
 
 
+def write_psd(name, planes, depth, rle, rng):
+    """planes: list of (h, w) integer arrays (R, G, B[, A[, extra]]); depth 8 or 16; rle: PackBits rows (8-bit only)"""
+    h, w = planes[0].shape
+    out = bytearray(b"8BPS" + struct.pack(">H6xHIIHH", 1, len(planes), h, w, depth, 3))
+    out += struct.pack(">I", 0) + struct.pack(">I", 6) + b"\x01\x02\x03\x04\x05\x06" + struct.pack(">I", 0)   # mode data | image resources | layers
+    out += struct.pack(">H", 1 if rle else 0)
+    if not rle:
+        for p_ in planes:
+            out += p_.astype(">u2" if depth == 16 else np.uint8).tobytes()
+    else:
+        rows, counts = [], []
+        for p_ in planes:
+            for y in range(h):
+                row, enc, i = [int(v) for v in p_[y]], bytearray(), 0
+                while i < w:
+                    run = 1
+                    while i + run < w and run < 128 and row[i + run] == row[i]:
+                        run += 1
+                    if run >= 2:
+                        enc += bytes([257 - run, row[i]]); i += run
+                    else:
+                        n = min(int(rng.integers(1, 6)), w - i)
+                        enc += bytes([n - 1] + row[i:i + n]); i += n
+                    if rng.integers(0, 9) == 0:
+                        enc += bytes([128])          # a no-op packet
+                rows.append(bytes(enc)); counts.append(len(enc))
+        out += b"".join(struct.pack(">H", c) for c in counts) + b"".join(rows)
+    open(os.path.join(OUT, name), "wb").write(bytes(out))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     rng = np.random.default_rng(20261004)
@@ -336,6 +366,15 @@ def main():
     write_exr_tiled("tiled_float_zip.exr", [("R", "float", fr), ("G", "float", fg), ("B", "float", fb), ("A", "half", fr * 0 + 1)], (10, 10), 3)
     write_exr_tiled("tiled_grey_zip.exr", [("Y", "half", np.round(fg * 8) / 8)], (64, 64), 3)
     write_exr_tiled("tiled_mipmap_zip.exr", [("R", "half", fb), ("G", "float", fr), ("B", "half", fg)], (8, 8), 3, mipmap=True)
+    # ---- PSD: raw and PackBits planes, 8 and 16 bits, with / without an alpha plane (un-matted from white), a fifth channel that is skipped
+    pr, pg, pb = (rng.integers(0, 256, (H, W)) for _ in range(3))
+    pr[: H // 2] = (runs * 7 % 256)[: H // 2]; pg[: H // 2] = (runs * 3 % 256)[: H // 2]
+    pa = rng.integers(0, 256, (H, W)); pa[:, : W // 3] = 255; pa[:, W // 3: W // 2] = 0
+    write_psd("rgb8_raw.psd", [pr, pg, pb], 8, False, rng)
+    write_psd("rgb8_rle.psd", [pr, pg, pb], 8, True, rng)
+    write_psd("rgba8_rle.psd", [pr, pg, pb, pa], 8, True, rng)
+    write_psd("rgba16_raw_5ch.psd", [pr * 257, pg * 255 + 9, pb * 256 + 255, pa * 257, pr], 16, False, rng)
+    write_psd("grey_pair_rle.psd", [pg, pb], 8, True, rng)          # two channels: blue reads 0
     print("wrote", len(os.listdir(OUT)), "files to", OUT)
 
 
