@@ -6,7 +6,7 @@
 //   .jpg / .jpeg  baseline JPEG (jpeg_decode.cpp), then the LDR -> linear conversion stb's stbi_loadf applies:
 //                 (float) pow(v / 255.0f, 2.2f)  (stb_image.h:1553,1849) — what the reference's ImageTextures hold.
 //   .png / .hdr   PNG (all colour types and bit depths, Adam7) and Radiance RGBE (png_decode.cpp), with stb's conventions
-//   .tga / .bmp / .psd   Truevision TGA, Windows BMP and Photoshop PSD (tga_bmp_decode.cpp), likewise
+//   .tga / .bmp / .psd / .gif   Truevision TGA, Windows BMP, Photoshop PSD and GIF (first frame) (tga_bmp_decode.cpp), likewise
 //   .exr          single-part scan-line or tiled OpenEXR, HALF / FLOAT / UINT channels, NONE / ZIPS / ZIP / PIZ (exr_decode.cpp);
 //                 three channels = R, G, B; one channel = their mean (image.cpp:70-72)
 // Other formats fail loudly.
@@ -27,6 +27,7 @@ HostImage read_hdr(const std::vector<uint8_t> &file, const std::string &name, in
 HostImage read_tga(const std::vector<uint8_t> &file, const std::string &name, int channels);   // tga_bmp_decode.cpp
 HostImage read_bmp(const std::vector<uint8_t> &file, const std::string &name, int channels);
 HostImage read_psd(const std::vector<uint8_t> &file, const std::string &name, int channels);
+HostImage read_gif(const std::vector<uint8_t> &file, const std::string &name, int channels);
 
 namespace {
 
@@ -107,17 +108,18 @@ HostImage read_image(const std::string &filename, int channels) {
         }
         return img;
     }
-    if (ext == ".png" || ext == ".hdr" || ext == ".tga" || ext == ".bmp" || ext == ".psd") {
+    if (ext == ".png" || ext == ".hdr" || ext == ".tga" || ext == ".bmp" || ext == ".psd" || ext == ".gif") {
         std::ifstream f(filename, std::ios::binary);
         if (!f) throw LjError(LJ_ERR_IO, "cannot open image: " + filename);
         std::vector<uint8_t> bytes((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
         if (ext == ".png") return read_png(bytes, filename, channels);
         if (ext == ".hdr") return read_hdr(bytes, filename, channels);
         if (ext == ".psd") return read_psd(bytes, filename, channels);
+        if (ext == ".gif") return read_gif(bytes, filename, channels);
         return ext == ".tga" ? read_tga(bytes, filename, channels) : read_bmp(bytes, filename, channels);
     }
-    // (the reference also passes .gif / .pic to stb_image, image.cpp:31-38; no shipped scene uses them)
-    throw LjError(LJ_ERR_UNSUPPORTED, "image format '" + ext + "' is not decoded by this build (JPEG, PNG, TGA, BMP, PSD, Radiance HDR, OpenEXR and PFM are): " + filename);
+    // (the reference also passes .pic to stb_image, image.cpp:31-38; no shipped scene uses it)
+    throw LjError(LJ_ERR_UNSUPPORTED, "image format '" + ext + "' is not decoded by this build (JPEG, PNG, TGA, BMP, PSD, GIF, Radiance HDR, OpenEXR and PFM are): " + filename);
 }
 
 // ------------------------------------------------------------------ imwrite (image.cpp:135-173)

@@ -1,5 +1,5 @@
-// Truevision TGA, Windows BMP and Photoshop PSD texture decoders of the front end.  The reference's imread3 / imread1 (image.cpp:28-133) hand
-// .tga, .bmp and .psd files to stb_image's float loader; these decoders are written from the file formats and reproduce what that loader returns, texel
+// Truevision TGA, Windows BMP, Photoshop PSD and GIF texture decoders of the front end.  The reference's imread3 / imread1 (image.cpp:28-133) hand
+// .tga, .bmp, .psd and .gif files to stb_image's float loader; these decoders are written from the file formats and reproduce what that loader returns, texel
 // for texel (pinned by tests/golden/image_decode.json, which the reference's own imread3 / imread1 produced for tests/assets/images/*):
 //   TGA   colour-mapped (types 1 / 9), true colour (2 / 10) and grey (3 / 11), raw or run-length packets; 8 / 15 / 16 / 24 / 32 bits per
 //         pixel or palette entry (15 / 16: five bits per channel, x * 255 / 31, the top bit ignored); rows bottom-up unless bit 5 of the
@@ -9,6 +9,9 @@
 //         run-length compressed files are refused (the reference's loader refuses them too)
 //   PSD   version 1, RGB mode, 8 or 16 bits per channel (the high byte is kept), raw or PackBits planes; the composite image only; with an
 //         alpha plane the colours are un-matted from white where 0 < alpha < 255, in float, as the reference's loader does
+//   GIF   87a / 89a, the FIRST frame only: global or local palette, LZW sub-blocks, interlaced rows, a frame smaller than the screen, a
+//         transparent index (such pixels stay black); pixels the frame does not cover take the background entry when its index is > 0 —
+//         with red and blue exchanged, which is what the reference's loader produces
 // then the conversion every LDR file goes through: luma (77 R + 150 G + 29 B) >> 8 for one channel, and (float) pow(v / 255.0f, 2.2f).
 #include "host_scene.h"
 #include <cmath>
@@ -265,6 +268,103 @@ HostImage read_psd(const std::vector<uint8_t> &file, const std::string &name, in
             }
         }
     return finish_ldr(px, (int)w, (int)h, 4, channels);
+}
+
+HostImage read_gif(const std::vector<uint8_t> &file, const std::string &name, int channels) {
+    Reader r{file, name};
+    if (r.u8() != 'G' || r.u8() != 'I' || r.u8() != 'F' || r.u8() != '8') throw LjError(LJ_ERR_PARSE, "not a GIF file: " + name);
+    const int ver = r.u8();
+    if ((ver != '7' && ver != '9') || r.u8() != 'a') throw LjError(LJ_ERR_PARSE, "not a GIF file: " + name);
+    const int W = (int)r.u16(), H = (int)r.u16(), flags = r.u8(), bgindex = r.u8();
+    r.u8();
+    if (W <= 0 || H <= 0) throw LjError(LJ_ERR_PARSE, "corrupt GIF (size): " + name);
+    uint8_t gpal[256][4] = {}, lpal[256][4] = {};   // entries as R, G, B, alpha
+    auto read_palette = [&](uint8_t pal[256][4], int n, int transparent) {
+        for (int i = 0; i < n; i++) { pal[i][0] = r.u8(); pal[i][1] = r.u8(); pal[i][2] = r.u8(); pal[i][3] = transparent == i ? 0 : 255; }
+    };
+    if (flags & 0x80) read_palette(gpal, 2 << (flags & 7), -1);
+    std::vector<uint8_t> px((size_t)W * H * 4, 0), touched((size_t)W * H, 0);
+    int eflags = 0, transparent = -1;
+    for (;;) {
+        if (r.p >= file.size()) throw LjError(LJ_ERR_PARSE, "GIF without an image: " + name);
+        const int tag = r.u8();
+        if (tag == 0x21) {
+            const int ext = r.u8();
+            if (ext == 0xF9) {   // graphic control: the transparent index (applies to the global palette at once, to a local one when it is read)
+                const int len = r.u8();
+                if (len != 4) throw LjError(LJ_ERR_PARSE, "corrupt GIF (graphic control block): " + name);
+                eflags = r.u8(); r.u16();
+                if (transparent >= 0) gpal[transparent][3] = 255;
+                if (eflags & 1) { transparent = r.u8(); gpal[transparent][3] = 0; } else { r.u8(); transparent = -1; }
+            }
+            for (int len; (len = r.u8()) != 0;) { if (r.p >= file.size()) throw LjError(LJ_ERR_PARSE, "truncated GIF extension: " + name); r.skip(len); }
+            continue;
+        }
+        if (tag == 0x3B) throw LjError(LJ_ERR_PARSE, "GIF without an image: " + name);
+        if (tag != 0x2C) throw LjError(LJ_ERR_PARSE, "corrupt GIF (block type): " + name);
+        const int x0 = (int)r.u16(), y0 = (int)r.u16(), w = (int)r.u16(), h = (int)r.u16();
+        if (x0 + w > W || y0 + h > H) throw LjError(LJ_ERR_PARSE, "corrupt GIF (frame outside the screen): " + name);
+        const int lflags = r.u8();
+        const uint8_t (*pal)[4];
+        if (lflags & 0x80) { read_palette(lpal, 2 << (lflags & 7), (eflags & 1) ? transparent : -1); pal = lpal; }
+        else if (flags & 0x80) pal = gpal;
+        else throw LjError(LJ_ERR_PARSE, "GIF without a colour table: " + name);
+        // rows in file order: top to bottom, or the four interlace passes (every 8th from 0, every 8th from 4, every 4th from 2, odd rows)
+        std::vector<int> rows;
+        if (lflags & 0x40) { for (int pass = 0; pass < 4; pass++) { const int start[4] = {0, 4, 2, 1}, step[4] = {8, 8, 4, 2}; for (int y = start[pass]; y < h; y += step[pass]) rows.push_back(y); } }
+        else for (int y = 0; y < h; y++) rows.push_back(y);
+        size_t n_out = 0;
+        const size_t n_px = (size_t)w * h;
+        auto emit = [&](int index) {
+            if (n_out >= n_px) return;
+            const int x = x0 + (int)(n_out % (size_t)w), y = y0 + rows[n_out / (size_t)w];
+            n_out++;
+            const size_t at = (size_t)y * W + x;
+            touched[at] = 1;
+            if (pal[index][3] > 128) { px[4 * at] = pal[index][0]; px[4 * at + 1] = pal[index][1]; px[4 * at + 2] = pal[index][2]; px[4 * at + 3] = pal[index][3]; }
+        };
+        // ---- LZW over the data sub-blocks
+        const int lzw_cs = r.u8();
+        if (lzw_cs > 12) throw LjError(LJ_ERR_PARSE, "corrupt GIF (code size): " + name);
+        struct Code { int16_t prefix; uint8_t first, suffix; };
+        std::vector<Code> codes(8192);
+        const int clear = 1 << lzw_cs;
+        for (int i = 0; i < clear; i++) { codes[i].prefix = -1; codes[i].first = codes[i].suffix = (uint8_t)i; }
+        int codesize = lzw_cs + 1, codemask = (1 << codesize) - 1, avail = clear + 2, oldcode = -1, valid_bits = 0, len = 0;
+        uint32_t bits = 0;
+        bool seen_clear = false, done = false;
+        std::vector<uint8_t> chain;
+        while (!done) {
+            if (valid_bits < codesize) {
+                if (len == 0) { len = r.u8(); if (len == 0) break; }
+                if (r.p >= file.size()) throw LjError(LJ_ERR_PARSE, "truncated GIF image data: " + name);
+                len--;
+                bits |= (uint32_t)r.u8() << valid_bits; valid_bits += 8;
+                continue;
+            }
+            const int code = (int)(bits & (uint32_t)codemask);
+            bits >>= codesize; valid_bits -= codesize;
+            if (code == clear) { codesize = lzw_cs + 1; codemask = (1 << codesize) - 1; avail = clear + 2; oldcode = -1; seen_clear = true; }
+            else if (code == clear + 1) { r.skip(len); for (int l; (l = r.u8()) > 0;) r.skip(l); done = true; }
+            else if (code <= avail) {
+                if (!seen_clear) throw LjError(LJ_ERR_PARSE, "corrupt GIF (no clear code): " + name);
+                if (oldcode >= 0) {
+                    if (avail >= 8192) throw LjError(LJ_ERR_PARSE, "corrupt GIF (too many codes): " + name);
+                    Code &c = codes[avail++];
+                    c.prefix = (int16_t)oldcode; c.first = codes[oldcode].first; c.suffix = (code == avail) ? c.first : codes[code].first;
+                } else if (code == avail) throw LjError(LJ_ERR_PARSE, "corrupt GIF (code before its definition): " + name);
+                chain.clear();
+                for (int c = code; c >= 0; c = codes[c].prefix) chain.push_back(codes[c].suffix);
+                for (size_t k = chain.size(); k-- > 0;) emit(chain[k]);
+                if ((avail & codemask) == 0 && avail <= 0x0FFF) { codesize++; codemask = (1 << codesize) - 1; }
+                oldcode = code;
+            } else throw LjError(LJ_ERR_PARSE, "corrupt GIF (code out of range): " + name);
+        }
+        if (bgindex > 0)   // what the frame did not cover takes the background entry — copied blue first into an R, G, B pixel by the reference's loader
+            for (size_t i = 0; i < (size_t)W * H; i++)
+                if (!touched[i]) { px[4 * i] = gpal[bgindex][2]; px[4 * i + 1] = gpal[bgindex][1]; px[4 * i + 2] = gpal[bgindex][0]; px[4 * i + 3] = 255; }
+        return finish_ldr(px, W, H, 4, channels);
+    }
 }
 
 } // namespace lj

@@ -285,6 +285,72 @@ def write_psd(name, planes, depth, rle, rng):
     open(os.path.join(OUT, name), "wb").write(bytes(out))
 
 
+def gif_lzw(indices, mcs):
+    """GIF's variable-width LZW (clear code first, again whenever the table is full), packed into data sub-blocks"""
+    clear, eoi = 1 << mcs, (1 << mcs) + 1
+    bits, nbits, data = 0, 0, bytearray()
+    def emit(code, size):
+        nonlocal bits, nbits
+        bits |= code << nbits
+        nbits += size
+        while nbits >= 8:
+            data.append(bits & 0xff); bits >>= 8; nbits -= 8
+    table = {(i,): i for i in range(clear)}
+    size, nxt = mcs + 1, eoi + 1
+    emit(clear, size)
+    w = ()
+    for k in indices:
+        k = int(k)
+        if w + (k,) in table:
+            w = w + (k,)
+            continue
+        emit(table[w], size)
+        table[w + (k,)] = nxt
+        nxt += 1
+        if nxt > (1 << size) and size < 12:
+            size += 1
+        if nxt == 4096:
+            emit(clear, size)
+            table = {(i,): i for i in range(clear)}
+            size, nxt = mcs + 1, eoi + 1
+        w = (k,)
+    if w:
+        emit(table[w], size)
+    emit(eoi, size)
+    if nbits:
+        data.append(bits & 0xff)
+    out = bytearray()
+    for i in range(0, len(data), 255):
+        blk = data[i:i + 255]
+        out += bytes([len(blk)]) + blk
+    return bytes(out) + b"\0"
+
+
+def write_gif(name, screen, frame, idx, gpal=None, lpal=None, bgindex=0, transparent=None, interlace=False, comment=False, version=b"89a"):
+    """screen (W, H); frame (x0, y0); idx: (h, w) palette indices; palettes: (2^n, 3) arrays"""
+    W_, H_ = screen
+    h, w = idx.shape
+    def pal_bits(p_):
+        return int(np.log2(len(p_))) - 1
+    out = bytearray(b"GIF" + version + struct.pack("<HHBBB", W_, H_, (0x80 | pal_bits(gpal)) if gpal is not None else 0, bgindex, 0))
+    if gpal is not None:
+        out += gpal.astype(np.uint8).tobytes()
+    if comment:
+        out += b"\x21\xfe\x05hello\x00"
+    if transparent is not None:
+        out += b"\x21\xf9\x04" + struct.pack("<BHB", 0x01, 7, transparent) + b"\0"
+    out += b"\x2c" + struct.pack("<HHHHB", frame[0], frame[1], w, h, (0x40 if interlace else 0) | ((0x80 | pal_bits(lpal)) if lpal is not None else 0))
+    if lpal is not None:
+        out += lpal.astype(np.uint8).tobytes()
+    rows = list(range(h))
+    if interlace:
+        rows = [y for start, step in ((0, 8), (4, 8), (2, 4), (1, 2)) for y in range(start, h, step)]
+    n_colours = len(lpal if lpal is not None else gpal)
+    mcs = max(2, int(np.log2(n_colours)))
+    out += bytes([mcs]) + gif_lzw(np.concatenate([idx[y] for y in rows]), mcs) + b"\x3b"
+    open(os.path.join(OUT, name), "wb").write(bytes(out))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     rng = np.random.default_rng(20261004)
@@ -375,6 +441,14 @@ def main():
     write_psd("rgba8_rle.psd", [pr, pg, pb, pa], 8, True, rng)
     write_psd("rgba16_raw_5ch.psd", [pr * 257, pg * 255 + 9, pb * 256 + 255, pa * 257, pr], 16, False, rng)
     write_psd("grey_pair_rle.psd", [pg, pb], 8, True, rng)          # two channels: blue reads 0
+    # ---- GIF (first frame): global / local palettes, interlace, transparency, a frame inside a larger screen with a background index,
+    # a picture large and random enough to fill the code table (clear code in mid-stream)
+    gp256, gp16, gp2, lp32 = rng.integers(0, 256, (256, 3)), rng.integers(0, 256, (16, 3)), rng.integers(0, 256, (2, 3)), rng.integers(0, 256, (32, 3))
+    write_gif("pal256.gif", (W, H), (0, 0), rng.integers(0, 256, (H, W)), gpal=gp256, version=b"87a")
+    write_gif("pal16_interlaced_transparent.gif", (W, H), (0, 0), (runs + rng.integers(0, 2, (H, W))) % 16, gpal=gp16, transparent=3, interlace=True, comment=True)
+    write_gif("local32_inset_bg.gif", (W + 9, H + 6), (4, 3), rng.integers(0, 32, (H, W)), gpal=gp16, lpal=lp32, bgindex=5, transparent=7)
+    write_gif("pal2_inset_interlaced.gif", (W, H), (1, 2), (xx[: H - 5, : W - 3] // 3 + yy[: H - 5, : W - 3]) % 2, gpal=gp2, bgindex=1, interlace=True)
+    write_gif("big_table_reset.gif", (160, 120), (0, 0), rng.integers(0, 256, (120, 160)), gpal=gp256)
     print("wrote", len(os.listdir(OUT)), "files to", OUT)
 
 
