@@ -166,10 +166,11 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
         HIP_CHECK(hipEventRecord(ctx->ev_begin, stream));
         int per_cu = ljd::mega_blocks_per_cu(sc->scfg);
         if (const char *e = getenv("LJ_TUNE_MEGA_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(e));
-        // camera samples a wave takes off the counter at a time: a multiple of 64 so that a wave's lanes share pixels; 1024 for a full
-        // frame, less when the pass is small (one rank's share of N: tools/shard_time.py) so that every wave still draws ~8 times and
-        // the grid ends together — a 1/8 share of the bench frame took 2.50 ms with 1.6 draws of 1024 per wave (ideal 1.65)
-        uint32_t grab_max = 1024;
+        // camera samples a wave takes off the counter at a time: a multiple of 64 so that a wave's lanes share pixels, chosen so that
+        // every wave draws ~16 times and the grid ends together — between 192 (below that the counter traffic shows) and 768:
+        // the full bench frame 13.28 ms at 1024 per draw, 13.06 at 768; a 1/8 share of it (one rank of eight: tools/shard_time.py)
+        // 2.50 ms at 1024, 2.00 at 192 (ideal 1.65)
+        uint32_t grab_max = 768, grab_min = 192;
         bool grab_fixed = false;
         if (const char *e = getenv("LJ_TUNE_MEGA_GRAB")) { grab_max = (uint32_t)std::max(64, atoi(e)) & ~63u; grab_fixed = true; }
         double mega_ms = 0;
@@ -183,10 +184,10 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
             HIP_CHECK(hipMemsetAsync(ctx->mega_state.p, 0, 64, stream));
             uint32_t grab = grab_max;
             if (!grab_fixed) {
-                uint64_t draws = 8;
+                uint64_t draws = 16;
                 if (const char *e = getenv("LJ_TUNE_MEGA_DRAWS")) draws = (uint64_t)std::max(1, atoi(e));
                 const uint64_t waves = (uint64_t)ctx->n_cus * per_cu * 4, per_draw = total / (waves * draws);
-                grab = (uint32_t)std::min<uint64_t>(grab_max, std::max<uint64_t>(64, per_draw & ~(uint64_t)63));
+                grab = (uint32_t)std::min<uint64_t>(grab_max, std::max<uint64_t>(grab_min, per_draw & ~(uint64_t)63));
             }
             // persistent grid: as many workgroups as stay resident, but no more waves than there are `grab`-sized pieces of work
             const uint64_t pieces = (total + grab - 1) / grab;
