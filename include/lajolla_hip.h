@@ -348,7 +348,7 @@ int lj_group_get_stats(const lj_group_scene *scene, LjStats *out);   /* sums ove
  * LJ_ERR_UNSUPPORTED. */
 int lj_image_write(const char *filename, int32_t width, int32_t height, const float *rgb);
 /* imread3() / imread1() (image.h:41-45, image.cpp:28-133), host only: decodes a texture file the way the reference's loaders do (JPEG, PNG,
- * TGA, BMP, PSD, GIF and Radiance HDR with stb_image's conventions incl. its (float) pow(v / 255, 2.2) for 8-bit data; OpenEXR; PFM) into `channels`
+ * TGA, BMP, PSD, GIF, PIC and Radiance HDR with stb_image's conventions incl. its (float) pow(v / 255, 2.2) for 8-bit data; OpenEXR; PFM) into `channels`
  * (1 or 3) floats per pixel, row-major, y = 0 at the top.  *data is owned by the library: release it with lj_image_free. */
 int lj_image_read(const char *filename, int32_t channels, int32_t *width, int32_t *height, float **data);
 void lj_image_free(float *data);

@@ -6,7 +6,7 @@
 //   .jpg / .jpeg  baseline JPEG (jpeg_decode.cpp), then the LDR -> linear conversion stb's stbi_loadf applies:
 //                 (float) pow(v / 255.0f, 2.2f)  (stb_image.h:1553,1849) — what the reference's ImageTextures hold.
 //   .png / .hdr   PNG (all colour types and bit depths, Adam7) and Radiance RGBE (png_decode.cpp), with stb's conventions
-//   .tga / .bmp / .psd / .gif   Truevision TGA, Windows BMP, Photoshop PSD and GIF (first frame) (tga_bmp_decode.cpp), likewise
+//   .tga / .bmp / .psd / .gif / .pic   Truevision TGA, Windows BMP, Photoshop PSD, GIF (first frame) and Softimage PIC (tga_bmp_decode.cpp), likewise
 //   .exr          single-part scan-line or tiled OpenEXR, HALF / FLOAT / UINT channels, NONE / ZIPS / ZIP / PIZ (exr_decode.cpp);
 //                 three channels = R, G, B; one channel = their mean (image.cpp:70-72)
 // Other formats fail loudly.
@@ -28,6 +28,7 @@ HostImage read_tga(const std::vector<uint8_t> &file, const std::string &name, in
 HostImage read_bmp(const std::vector<uint8_t> &file, const std::string &name, int channels);
 HostImage read_psd(const std::vector<uint8_t> &file, const std::string &name, int channels);
 HostImage read_gif(const std::vector<uint8_t> &file, const std::string &name, int channels);
+HostImage read_pic(const std::vector<uint8_t> &file, const std::string &name, int channels);
 
 namespace {
 
@@ -108,7 +109,7 @@ HostImage read_image(const std::string &filename, int channels) {
         }
         return img;
     }
-    if (ext == ".png" || ext == ".hdr" || ext == ".tga" || ext == ".bmp" || ext == ".psd" || ext == ".gif") {
+    if (ext == ".png" || ext == ".hdr" || ext == ".tga" || ext == ".bmp" || ext == ".psd" || ext == ".gif" || ext == ".pic") {
         std::ifstream f(filename, std::ios::binary);
         if (!f) throw LjError(LJ_ERR_IO, "cannot open image: " + filename);
         std::vector<uint8_t> bytes((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
@@ -116,10 +117,11 @@ HostImage read_image(const std::string &filename, int channels) {
         if (ext == ".hdr") return read_hdr(bytes, filename, channels);
         if (ext == ".psd") return read_psd(bytes, filename, channels);
         if (ext == ".gif") return read_gif(bytes, filename, channels);
+        if (ext == ".pic") return read_pic(bytes, filename, channels);
         return ext == ".tga" ? read_tga(bytes, filename, channels) : read_bmp(bytes, filename, channels);
     }
-    // (the reference also passes .pic to stb_image, image.cpp:31-38; no shipped scene uses it)
-    throw LjError(LJ_ERR_UNSUPPORTED, "image format '" + ext + "' is not decoded by this build (JPEG, PNG, TGA, BMP, PSD, GIF, Radiance HDR, OpenEXR and PFM are): " + filename);
+    // (every extension the reference passes to stb_image or tinyexr, image.cpp:31-38,54, is decoded above)
+    throw LjError(LJ_ERR_UNSUPPORTED, "image format '" + ext + "' is not decoded by this build (JPEG, PNG, TGA, BMP, PSD, GIF, PIC, Radiance HDR, OpenEXR and PFM are): " + filename);
 }
 
 // ------------------------------------------------------------------ imwrite (image.cpp:135-173)

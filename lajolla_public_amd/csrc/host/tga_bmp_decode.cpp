@@ -1,5 +1,5 @@
-// Truevision TGA, Windows BMP, Photoshop PSD and GIF texture decoders of the front end.  The reference's imread3 / imread1 (image.cpp:28-133) hand
-// .tga, .bmp, .psd and .gif files to stb_image's float loader; these decoders are written from the file formats and reproduce what that loader returns, texel
+// Truevision TGA, Windows BMP, Photoshop PSD, GIF and Softimage PIC texture decoders of the front end.  The reference's imread3 / imread1
+// (image.cpp:28-133) hand .tga, .bmp, .psd, .gif and .pic files to stb_image's float loader; these decoders are written from the file formats and reproduce what that loader returns, texel
 // for texel (pinned by tests/golden/image_decode.json, which the reference's own imread3 / imread1 produced for tests/assets/images/*):
 //   TGA   colour-mapped (types 1 / 9), true colour (2 / 10) and grey (3 / 11), raw or run-length packets; 8 / 15 / 16 / 24 / 32 bits per
 //         pixel or palette entry (15 / 16: five bits per channel, x * 255 / 31, the top bit ignored); rows bottom-up unless bit 5 of the
@@ -12,6 +12,8 @@
 //   GIF   87a / 89a, the FIRST frame only: global or local palette, LZW sub-blocks, interlaced rows, a frame smaller than the screen, a
 //         transparent index (such pixels stay black); pixels the frame does not cover take the background entry when its index is > 0 —
 //         with red and blue exchanged, which is what the reference's loader produces
+//   PIC   Softimage: a chain of 8-bit channel packets (any split of R, G, B, A), each raw, pure run-length or mixed run-length per scan line;
+//         a channel no packet carries reads 255
 // then the conversion every LDR file goes through: luma (77 R + 150 G + 29 B) >> 8 for one channel, and (float) pow(v / 255.0f, 2.2f).
 #include "host_scene.h"
 #include <cmath>
@@ -365,6 +367,62 @@ HostImage read_gif(const std::vector<uint8_t> &file, const std::string &name, in
                 if (!touched[i]) { px[4 * i] = gpal[bgindex][2]; px[4 * i + 1] = gpal[bgindex][1]; px[4 * i + 2] = gpal[bgindex][0]; px[4 * i + 3] = 255; }
         return finish_ldr(px, W, H, 4, channels);
     }
+}
+
+HostImage read_pic(const std::vector<uint8_t> &file, const std::string &name, int channels) {
+    static const uint8_t magic[4] = {0x53, 0x80, 0xF6, 0x34};
+    if (file.size() < 104 || memcmp(file.data(), magic, 4) != 0 || memcmp(file.data() + 88, "PICT", 4) != 0) throw LjError(LJ_ERR_PARSE, "not a Softimage PIC file: " + name);
+    Reader r{file, name};
+    r.skip(92);
+    auto be16 = [&]() { const uint32_t a = r.u8(); return (int)((a << 8) | r.u8()); };
+    const int w = be16(), h = be16();
+    r.skip(8);   // ratio, fields, pad
+    if (w <= 0 || h <= 0) throw LjError(LJ_ERR_PARSE, "corrupt PIC (size): " + name);
+    struct Packet { int type, channel; };
+    std::vector<Packet> packets;
+    for (bool chained = true; chained;) {
+        if (packets.size() == 10) throw LjError(LJ_ERR_PARSE, "corrupt PIC (too many packets): " + name);
+        chained = r.u8() != 0;
+        const int size = r.u8();
+        Packet pk; pk.type = r.u8(); pk.channel = r.u8();
+        if (r.p >= file.size()) throw LjError(LJ_ERR_PARSE, "truncated PIC (packets): " + name);
+        if (size != 8) throw LjError(LJ_ERR_UNSUPPORTED, "PIC channels that are not 8 bits wide: " + name);
+        if (pk.type > 2) throw LjError(LJ_ERR_UNSUPPORTED, "PIC packet compression type: " + name);
+        packets.push_back(pk);
+    }
+    std::vector<uint8_t> px((size_t)w * h * 4, 0xff);
+    auto read_value = [&](int channel, uint8_t *dst) {   // the channels of the mask, most significant bit = red
+        for (int i = 0, mask = 0x80; i < 4; i++, mask >>= 1)
+            if (channel & mask) { if (r.p >= file.size()) throw LjError(LJ_ERR_PARSE, "truncated PIC (pixel data): " + name); dst[i] = r.u8(); }
+    };
+    auto copy_value = [](int channel, uint8_t *dst, const uint8_t *src) { for (int i = 0, mask = 0x80; i < 4; i++, mask >>= 1) if (channel & mask) dst[i] = src[i]; };
+    for (int y = 0; y < h; y++)
+        for (const Packet &pk : packets) {
+            uint8_t *dst = &px[(size_t)y * w * 4];
+            if (pk.type == 0) { for (int x = 0; x < w; x++, dst += 4) read_value(pk.channel, dst); continue; }
+            for (int left = w; left > 0;) {
+                int count = r.u8();
+                if (r.p >= file.size()) throw LjError(LJ_ERR_PARSE, "truncated PIC (run): " + name);
+                uint8_t value[4] = {0, 0, 0, 0};
+                if (pk.type == 1) {   // pure run-length: count, value
+                    if (count == 0) throw LjError(LJ_ERR_PARSE, "corrupt PIC (empty run): " + name);
+                    if (count > left) count = left;
+                    read_value(pk.channel, value);
+                    for (int i = 0; i < count; i++, dst += 4) copy_value(pk.channel, dst, value);
+                } else if (count >= 128) {   // mixed: a repeated value ...
+                    count = count == 128 ? be16() : count - 127;
+                    if (count > left) throw LjError(LJ_ERR_PARSE, "corrupt PIC (scan line overrun): " + name);
+                    read_value(pk.channel, value);
+                    for (int i = 0; i < count; i++, dst += 4) copy_value(pk.channel, dst, value);
+                } else {   // ... or count + 1 literal values
+                    count++;
+                    if (count > left) throw LjError(LJ_ERR_PARSE, "corrupt PIC (scan line overrun): " + name);
+                    for (int i = 0; i < count; i++, dst += 4) read_value(pk.channel, dst);
+                }
+                left -= count;
+            }
+        }
+    return finish_ldr(px, w, h, 4, channels);
 }
 
 } // namespace lj

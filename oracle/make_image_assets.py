@@ -351,6 +351,34 @@ def write_gif(name, screen, frame, idx, gpal=None, lpal=None, bgindex=0, transpa
     open(os.path.join(OUT, name), "wb").write(bytes(out))
 
 
+def write_pic(name, rgba, packets, rng):
+    """rgba: (h, w, 4) bytes; packets: list of (type, channel mask) — type 0 raw, 1 pure run-length, 2 mixed run-length; mask 0x80 R ... 0x10 A"""
+    h, w, _ = rgba.shape
+    out = bytearray(b"\x53\x80\xf6\x34" + struct.pack(">f", 0.0) + b"made by oracle/make_image_assets.py".ljust(80, b"\0") + b"PICT" + struct.pack(">HHfHH", w, h, 1.0, 3, 0))
+    for i, (t, ch) in enumerate(packets):
+        out += bytes([1 if i + 1 < len(packets) else 0, 8, t, ch])
+    for y in range(h):
+        for t, ch in packets:
+            sel = [k for k in range(4) if ch & (0x80 >> k)]
+            vals = [bytes(int(rgba[y, x, k]) for k in sel) for x in range(w)]
+            if t == 0:
+                out += b"".join(vals)
+                continue
+            i = 0
+            while i < w:
+                run = 1
+                while i + run < w and run < (255 if t == 1 else 300) and vals[i + run] == vals[i]:
+                    run += 1
+                if t == 1:
+                    out += bytes([run]) + vals[i]; i += run
+                elif run >= 2:
+                    out += (bytes([128]) + struct.pack(">H", run) if run > 128 or rng.integers(0, 4) == 0 else bytes([run + 127])) + vals[i]; i += run
+                else:
+                    n = min(int(rng.integers(1, 7)), w - i)
+                    out += bytes([n - 1]) + b"".join(vals[i:i + n]); i += n
+    open(os.path.join(OUT, name), "wb").write(bytes(out))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     rng = np.random.default_rng(20261004)
@@ -449,6 +477,13 @@ def main():
     write_gif("local32_inset_bg.gif", (W + 9, H + 6), (4, 3), rng.integers(0, 32, (H, W)), gpal=gp16, lpal=lp32, bgindex=5, transparent=7)
     write_gif("pal2_inset_interlaced.gif", (W, H), (1, 2), (xx[: H - 5, : W - 3] // 3 + yy[: H - 5, : W - 3]) % 2, gpal=gp2, bgindex=1, interlace=True)
     write_gif("big_table_reset.gif", (160, 120), (0, 0), rng.integers(0, 256, (120, 160)), gpal=gp256)
+    # ---- Softimage PIC: raw / pure run-length / mixed run-length packets, channels split over packets, with and without alpha
+    prgba = np.stack([pr, pg, pb, pa], -1)
+    write_pic("rgb_mixed.pic", prgba, [(2, 0xE0)], rng)
+    write_pic("rgba_raw_alpha_rle.pic", prgba, [(0, 0xE0), (1, 0x10)], rng)
+    write_pic("split_channels.pic", prgba, [(1, 0x80), (2, 0x60)], rng)
+    wide = np.zeros((5, 400, 4), np.int64); wide[..., 0] = 7; wide[2, 100:, 1] = 200; wide[..., 2] = (np.arange(400) // 150) * 90
+    write_pic("wide_long_runs.pic", wide, [(2, 0xE0)], rng)
     print("wrote", len(os.listdir(OUT)), "files to", OUT)
 
 
