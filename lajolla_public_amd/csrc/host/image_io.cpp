@@ -3,7 +3,7 @@
 //
 // Decoders implemented here, from the format specifications (no third-party code):
 //   .pfm          portable float map (colour "PF" / grey "Pf"), bottom-up, endianness by the sign of the scale
-//   .jpg / .jpeg  baseline JPEG (jpeg_decode.cpp), then the LDR -> linear conversion stb's stbi_loadf applies:
+//   .jpg / .jpeg  baseline and progressive JPEG (jpeg_decode.cpp), then the LDR -> linear conversion stb's stbi_loadf applies:
 //                 (float) pow(v / 255.0f, 2.2f)  (stb_image.h:1553,1849) — what the reference's ImageTextures hold.
 //   .png / .hdr   PNG (all colour types and bit depths, Adam7) and Radiance RGBE (png_decode.cpp), with stb's conventions
 //   .tga / .bmp / .psd / .gif / .pic   Truevision TGA, Windows BMP, Photoshop PSD, GIF (first frame) and Softimage PIC (tga_bmp_decode.cpp), likewise
@@ -20,7 +20,7 @@
 
 namespace lj {
 
-std::vector<uint8_t> decode_jpeg_rgb8(const std::vector<uint8_t> &file, int &width, int &height, const std::string &name);
+std::vector<uint8_t> decode_jpeg_rgb8(const std::vector<uint8_t> &file, int &width, int &height, const std::string &name, std::vector<uint8_t> *grey);
 HostImage decode_exr_rgb(const std::vector<uint8_t> &file, const std::string &name);
 HostImage read_png(const std::vector<uint8_t> &file, const std::string &name, int channels);   // png_decode.cpp
 HostImage read_hdr(const std::vector<uint8_t> &file, const std::string &name, int channels);
@@ -98,14 +98,15 @@ HostImage read_image(const std::string &filename, int channels) {
         if (!f) throw LjError(LJ_ERR_IO, "cannot open image: " + filename);
         std::vector<uint8_t> bytes((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
         int w = 0, h = 0;
-        std::vector<uint8_t> rgb = decode_jpeg_rgb8(bytes, w, h, filename);
+        std::vector<uint8_t> y8;
+        std::vector<uint8_t> rgb = decode_jpeg_rgb8(bytes, w, h, filename, channels == 1 ? &y8 : nullptr);
         HostImage img; img.width = w; img.height = h; img.channels = channels == 1 ? 1 : 3;
         img.data.resize((size_t)w * h * img.channels);
-        // stbi_loadf(..., req_comp): 3 -> RGB; 1 -> luma (77 R + 150 G + 29 B) >> 8 of the decoded RGB (stb_image.h stbi__compute_y)
+        // stbi_loadf(..., req_comp): 3 -> RGB; 1 -> the Y plane of a YCbCr file (or the luma of an RGB-coded one): jpeg_decode.cpp
         const float gamma = 2.2f;
         for (size_t i = 0; i < (size_t)w * h; i++) {
             if (img.channels == 3) { for (int c = 0; c < 3; c++) img.data[3 * i + c] = (float)std::pow((double)(rgb[3 * i + c] / 255.0f), (double)gamma); }
-            else { uint8_t y = (uint8_t)((rgb[3 * i] * 77 + rgb[3 * i + 1] * 150 + 29 * rgb[3 * i + 2]) >> 8); img.data[i] = (float)std::pow((double)(y / 255.0f), (double)gamma); }
+            else img.data[i] = (float)std::pow((double)(y8[i] / 255.0f), (double)gamma);
         }
         return img;
     }

@@ -1,4 +1,4 @@
-// Baseline JPEG (ITU-T T.81, sequential DCT, Huffman, 8-bit) decoder for texture input.
+// JPEG (ITU-T T.81: sequential and progressive DCT, Huffman, 8-bit; interleaved and per-component scans) decoder for texture input.
 //
 // The reference loads LDR textures through stb_image (image.cpp:44,96), so texel values depend on three choices the
 // JPEG standard leaves to the decoder.  We make the same ones so that the decoded texels are bit-identical to what
@@ -7,7 +7,8 @@
 //     two passes, 2 extra bits kept between them, +128 level shift folded into the final rounding;
 //   * 2x2 chroma upsampling uses the triangle filter  (3*near + far) per axis: (3*t_i + t_{i±1} + 8) >> 4;
 //   * YCbCr -> RGB in 20-bit fixed point with the BT.601 constants quantised to 12 bits.
-// Progressive / arithmetic-coded / 12-bit files are rejected with LJ_ERR_UNSUPPORTED.
+// Progressive files collect their coefficients over all scans (DC / AC bands, successive approximation) and go through the same transform.
+// Arithmetic-coded / lossless / hierarchical / 12-bit files are rejected with LJ_ERR_UNSUPPORTED (the reference's loader refuses them too).
 #include "host_scene.h"
 #include <cstring>
 #include <fstream>
@@ -26,7 +27,7 @@ struct Huff {
     }
 };
 
-struct Component { int id, h, v, tq, td, ta; int w2, h2; std::vector<uint8_t> data; int dc_pred; };
+struct Component { int id, h, v, tq, td, ta; int x, y; int w2, h2; std::vector<uint8_t> data; std::vector<short> coeff; int dc_pred; };   // x, y: its size in samples; w2, h2: padded to whole MCUs
 
 struct BitReader {
     const uint8_t *p, *end; uint32_t buf = 0; int nbits = 0; bool hit_marker = false;
@@ -131,8 +132,10 @@ inline int fixed12(float x) { return ((int)(x * 4096.0f + 0.5f)) << 8; }
 
 } // namespace
 
-// returns 8-bit interleaved RGB (or grey replicated), width*height*3
-std::vector<uint8_t> decode_jpeg_rgb8(const std::vector<uint8_t> &file, int &width, int &height, const std::string &name) {
+// returns 8-bit interleaved RGB (or grey replicated), width*height*3.  `grey` (optional): the one-channel image the reference's loader
+// returns when one channel is asked for — the Y plane of a YCbCr file (the chroma planes are not even upsampled), the luma
+// (77 R + 150 G + 29 B) >> 8 of an RGB-coded file, the samples of a grey file.
+std::vector<uint8_t> decode_jpeg_rgb8(const std::vector<uint8_t> &file, int &width, int &height, const std::string &name, std::vector<uint8_t> *grey) {
     auto bad = [&](const char *why) -> LjError { return LjError(LJ_ERR_PARSE, std::string("JPEG ") + name + ": " + why); };
     size_t pos = 0, n = file.size();
     if (n < 4 || file[0] != 0xFF || file[1] != 0xD8) throw bad("not a JPEG (no SOI)");
@@ -140,20 +143,126 @@ std::vector<uint8_t> decode_jpeg_rgb8(const std::vector<uint8_t> &file, int &wid
     uint16_t qt[4][64]; bool have_qt[4] = {false, false, false, false};
     Huff hdc[4], hac[4]; bool have_dc[4] = {false}, have_ac[4] = {false};
     std::vector<Component> comp;
-    int restart_interval = 0, hmax = 1, vmax = 1;
-    bool jfif = false; int app14_transform = -1;
+    int restart_interval = 0, hmax = 1, vmax = 1, mcux = 0, mcuy = 0, scans = 0;
+    bool jfif = false, progressive = false; int app14_transform = -1;
     width = height = 0;
     auto rd16 = [&](size_t p) { return (file[p] << 8) | file[p + 1]; };
-    for (;;) {
+
+    // ---- one scan's entropy-coded data, from `at`; returns where the reader stopped (at the marker that ends the scan)
+    // Sequential files: every block is complete after its scan and is transformed at once.  Progressive files (T.81 Annex G): a scan carries
+    // the DC coefficients (all components interleaved, or one) or a band Ss..Se of one component's AC coefficients, first at precision Al,
+    // then one bit at a time (Ah = Al + 1); coefficients collect in `coeff` and are dequantised and transformed after the last scan.
+    auto decode_scan = [&](size_t at, const std::vector<int> &order, int Ss, int Se, int Ah, int Al) -> size_t {
+        BitReader br; br.p = &file[at]; br.end = file.data() + n;
+        int todo = restart_interval ? restart_interval : 0x7fffffff, eob_run = 0;
+        for (auto &c : comp) c.dc_pred = 0;
+        short block[64];
+        auto refine = [&](short &v, short bit) { if (v != 0 && br.bit() && (v & bit) == 0) v = (short)(v > 0 ? v + bit : v - bit); };
+        auto one_block = [&](Component &c, int bx, int by) {   // block (bx, by) of component c, in blocks
+            if (!progressive) {
+                memset(block, 0, sizeof block);
+                int t = decode_symbol(br, hdc[c.td]);
+                if (t > 11) throw bad("bad DC magnitude");
+                int diff = t ? extend(br.bits(t), t) : 0;
+                c.dc_pred += diff;
+                block[0] = (short)(c.dc_pred * qt[c.tq][0]);
+                for (int k = 1; k < 64;) {
+                    int rs = decode_symbol(br, hac[c.ta]);
+                    int r = rs >> 4, sz = rs & 15;
+                    if (sz == 0) { if (r != 15) break; k += 16; continue; }
+                    k += r;
+                    if (k > 63) throw bad("AC index out of range");
+                    block[kZigzag[k]] = (short)(extend(br.bits(sz), sz) * qt[c.tq][kZigzag[k]]);
+                    k++;
+                }
+                idct_block(&c.data[(size_t)by * 8 * c.w2 + (size_t)bx * 8], c.w2, block);
+                return;
+            }
+            short *d = &c.coeff[((size_t)by * (c.w2 / 8) + bx) * 64];
+            if (Ss == 0) {   // DC
+                if (Se != 0) throw bad("progressive scan mixes DC and AC coefficients");
+                if (Ah == 0) {
+                    int t = decode_symbol(br, hdc[c.td]);
+                    if (t > 15) throw bad("bad DC magnitude");
+                    c.dc_pred += t ? extend(br.bits(t), t) : 0;
+                    d[0] = (short)(c.dc_pred * (1 << Al));
+                } else if (br.bit()) d[0] = (short)(d[0] + (1 << Al));
+                return;
+            }
+            if (Ah == 0) {   // AC band, first pass
+                if (eob_run) { eob_run--; return; }
+                int k = Ss;
+                do {
+                    int rs = decode_symbol(br, hac[c.ta]);
+                    int r = rs >> 4, sz = rs & 15;
+                    if (sz == 0) {
+                        if (r < 15) { eob_run = (1 << r); if (r) eob_run += br.bits(r); eob_run--; break; }
+                        k += 16;
+                    } else {
+                        k += r;
+                        if (k > 63) throw bad("AC index out of range");
+                        d[kZigzag[k++]] = (short)(extend(br.bits(sz), sz) * (1 << Al));
+                    }
+                } while (k <= Se);
+                return;
+            }
+            const short bit = (short)(1 << Al);   // AC band, one more bit
+            if (eob_run) { eob_run--; for (int k = Ss; k <= Se; k++) refine(d[kZigzag[k]], bit); return; }
+            int k = Ss;
+            do {
+                int rs = decode_symbol(br, hac[c.ta]);
+                int r = rs >> 4, sz = rs & 15;
+                if (sz == 0) {
+                    if (r < 15) { eob_run = (1 << r) - 1; if (r) eob_run += br.bits(r); r = 64; }   // end of band: the rest is refinement only
+                } else {
+                    if (sz != 1) throw bad("bad refinement code");
+                    sz = br.bit() ? bit : -bit;
+                }
+                while (k <= Se) {   // pass r still-zero coefficients (refining the non-zero ones on the way), then place the new one
+                    short &v = d[kZigzag[k++]];
+                    if (v != 0) refine(v, bit);
+                    else { if (r == 0) { v = (short)sz; break; } r--; }
+                }
+            } while (k <= Se);
+        };
+        // after `restart_interval` MCUs: realign behind the restart marker and reset the predictors; false when what follows is not a restart
+        // marker (the scan is over — or cut short: what was decoded stands, as in the reference's loader)
+        auto restart = [&]() -> bool {
+            br.reset();
+            const uint8_t *q = br.p;
+            while (q + 1 < br.end && !(q[0] == 0xFF && q[1] != 0x00 && q[1] != 0xFF)) q++;
+            if (!(q + 1 < br.end && q[1] >= 0xD0 && q[1] <= 0xD7)) { br.p = q; return false; }
+            br.p = q + 2;
+            for (auto &c : comp) c.dc_pred = 0;
+            eob_run = 0;
+            todo = restart_interval;
+            return true;
+        };
+        if (order.size() == 1) {   // one component: its blocks in raster order, as many as its own size needs
+            Component &c = comp[order[0]];
+            const int bw = (c.x + 7) >> 3, bh = (c.y + 7) >> 3;
+            for (int by = 0; by < bh; by++) for (int bx = 0; bx < bw; bx++) { one_block(c, bx, by); if (--todo <= 0 && !restart()) return (size_t)(br.p - file.data()); }
+        } else {
+            if (progressive && Ss != 0) throw bad("interleaved progressive AC scan");
+            for (int my = 0; my < mcuy; my++) for (int mx = 0; mx < mcux; mx++) {
+                for (int k : order) { Component &c = comp[k]; for (int y = 0; y < c.v; y++) for (int x = 0; x < c.h; x++) one_block(c, mx * c.h + x, my * c.v + y); }
+                if (--todo <= 0 && !restart()) return (size_t)(br.p - file.data());
+            }
+        }
+        return (size_t)(br.p - file.data());
+    };
+
+    bool done = false;
+    while (!done) {
         while (pos < n && file[pos] != 0xFF) pos++;
         while (pos < n && file[pos] == 0xFF) pos++;
-        if (pos >= n) throw bad("unexpected end of file");
+        if (pos >= n) { if (scans) break; throw bad("unexpected end of file"); }
         int m = file[pos++];
-        if (m == 0xD9) throw bad("EOI before any scan");
+        if (m == 0xD9) { if (scans) break; throw bad("EOI before any scan"); }
         if (m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;
-        if (pos + 2 > n) throw bad("truncated segment");
+        if (pos + 2 > n) { if (scans) break; throw bad("truncated segment"); }
         int len = rd16(pos);
-        if (len < 2 || pos + len > n) throw bad("bad segment length");
+        if (len < 2 || pos + len > n) { if (scans) break; throw bad("bad segment length"); }
         size_t seg = pos + 2, seg_end = pos + len;
         if (m == 0xDB) {  // DQT
             while (seg < seg_end) {
@@ -173,7 +282,9 @@ std::vector<uint8_t> decode_jpeg_rgb8(const std::vector<uint8_t> &file, int &wid
                 memcpy(h.sym, &file[seg], total); seg += total;
                 h.build(); (tc ? have_ac : have_dc)[th] = true;
             }
-        } else if (m == 0xC0 || m == 0xC1) {  // SOF0 / SOF1: sequential Huffman
+        } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {  // SOF0 / SOF1: sequential Huffman; SOF2: progressive Huffman
+            if (!comp.empty()) throw bad("second frame header");
+            progressive = m == 0xC2;
             if (file[seg] != 8) throw LjError(LJ_ERR_UNSUPPORTED, "JPEG " + name + ": only 8-bit samples are supported");
             height = rd16(seg + 1); width = rd16(seg + 3);
             int nc = file[seg + 5];
@@ -184,64 +295,54 @@ std::vector<uint8_t> decode_jpeg_rgb8(const std::vector<uint8_t> &file, int &wid
                 if (comp[i].h < 1 || comp[i].h > 4 || comp[i].v < 1 || comp[i].v > 4 || comp[i].tq > 3) throw bad("bad SOF component");
                 hmax = std::max(hmax, comp[i].h); vmax = std::max(vmax, comp[i].v);
             }
-        } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
-            throw LjError(LJ_ERR_UNSUPPORTED, "JPEG " + name + ": progressive / lossless / arithmetic-coded files are not supported");
+            mcux = (width + 8 * hmax - 1) / (8 * hmax); mcuy = (height + 8 * vmax - 1) / (8 * vmax);
+            for (auto &c : comp) {
+                c.x = (width * c.h + hmax - 1) / hmax; c.y = (height * c.v + vmax - 1) / vmax;
+                c.w2 = mcux * c.h * 8; c.h2 = mcuy * c.v * 8; c.data.assign((size_t)c.w2 * c.h2, 0); c.dc_pred = 0;
+                if (progressive) c.coeff.assign((size_t)c.w2 * c.h2, 0);
+            }
+        } else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+            throw LjError(LJ_ERR_UNSUPPORTED, "JPEG " + name + ": lossless / hierarchical / arithmetic-coded files are not supported");
         } else if (m == 0xDD) { restart_interval = rd16(seg); }
         else if (m == 0xE0) { if (len >= 7 && !memcmp(&file[seg], "JFIF\0", 5)) jfif = true; }
         else if (m == 0xEE) { if (len >= 14 && !memcmp(&file[seg], "Adobe\0", 6)) app14_transform = file[seg + 11]; }
-        else if (m == 0xDA) {  // SOS: baseline files have one interleaved scan
+        else if (m == 0xDA) {  // SOS
             if (comp.empty()) throw bad("SOS before SOF");
             int ns = file[seg];
-            if (ns != (int)comp.size()) throw LjError(LJ_ERR_UNSUPPORTED, "JPEG " + name + ": non-interleaved scans are not supported");
+            if (ns < 1 || ns > (int)comp.size() || seg + 1 + 2 * ns + 3 > seg_end) throw bad("bad scan header");
+            std::vector<int> order;
             for (int i = 0; i < ns; i++) {
                 int id = file[seg + 1 + 2 * i], tt = file[seg + 2 + 2 * i], k = -1;
                 for (int c = 0; c < (int)comp.size(); c++) if (comp[c].id == id) k = c;
                 if (k < 0) throw bad("SOS references an unknown component");
                 comp[k].td = tt >> 4; comp[k].ta = tt & 15;
-                if (comp[k].td > 3 || comp[k].ta > 3 || !have_dc[comp[k].td] || !have_ac[comp[k].ta] || !have_qt[comp[k].tq]) throw bad("scan uses an undefined table");
+                if (comp[k].td > 3 || comp[k].ta > 3) throw bad("scan uses an undefined table");
+                order.push_back(k);
             }
-            pos = seg_end;
-            break;
+            const int Ss = file[seg + 1 + 2 * ns], Se = file[seg + 2 + 2 * ns], Ah = file[seg + 3 + 2 * ns] >> 4, Al = file[seg + 3 + 2 * ns] & 15;
+            if (progressive) { if (Ss > 63 || Se > 63 || Ss > Se || Ah > 13 || Al > 13) throw bad("bad progressive scan parameters"); }
+            else if (Ss != 0 || Ah != 0 || Al != 0) throw bad("bad sequential scan parameters");
+            for (int k : order) {   // the tables this scan decodes with
+                const bool need_dc = !progressive || Ss == 0, need_ac = !progressive || Ss > 0;
+                if ((need_dc && !(progressive && Ah) && !have_dc[comp[k].td]) || (need_ac && !have_ac[comp[k].ta]) || !have_qt[comp[k].tq]) throw bad("scan uses an undefined table");
+            }
+            pos = decode_scan(seg_end, order, Ss, Se, Ah, Al);
+            scans++;
+            continue;
         }
         pos = seg_end;
     }
-    // ---- entropy-coded segment
-    const int mcu_w = 8 * hmax, mcu_h = 8 * vmax;
-    const int mcux = (width + mcu_w - 1) / mcu_w, mcuy = (height + mcu_h - 1) / mcu_h;
-    for (auto &c : comp) { c.w2 = mcux * c.h * 8; c.h2 = mcuy * c.v * 8; c.data.assign((size_t)c.w2 * c.h2, 0); c.dc_pred = 0; }
-    BitReader br; br.p = &file[pos]; br.end = file.data() + n;
-    int todo = restart_interval ? restart_interval : 0x7fffffff;
-    short block[64];
-    for (int my = 0; my < mcuy; my++) for (int mx = 0; mx < mcux; mx++) {
-        for (auto &c : comp) for (int by = 0; by < c.v; by++) for (int bx = 0; bx < c.h; bx++) {
-            memset(block, 0, sizeof block);
-            int t = decode_symbol(br, hdc[c.td]);
-            if (t > 11) throw bad("bad DC magnitude");
-            int diff = t ? extend(br.bits(t), t) : 0;
-            c.dc_pred += diff;
-            block[0] = (short)(c.dc_pred * qt[c.tq][0]);
-            for (int k = 1; k < 64;) {
-                int rs = decode_symbol(br, hac[c.ta]);
-                int r = rs >> 4, s = rs & 15;
-                if (s == 0) { if (r != 15) break; k += 16; continue; }
-                k += r;
-                if (k > 63) throw bad("AC index out of range");
-                block[kZigzag[k]] = (short)(extend(br.bits(s), s) * qt[c.tq][kZigzag[k]]);
-                k++;
+    if (comp.empty() || !scans) throw bad("no image data");
+    if (progressive)   // every coefficient is in: dequantise and transform
+        for (auto &c : comp)
+            for (int by = 0; by < c.h2 / 8; by++) for (int bx = 0; bx < c.w2 / 8; bx++) {
+                short *d = &c.coeff[((size_t)by * (c.w2 / 8) + bx) * 64];
+                for (int i = 0; i < 64; i++) d[i] = (short)(d[i] * qt[c.tq][i]);
+                idct_block(&c.data[(size_t)by * 8 * c.w2 + (size_t)bx * 8], c.w2, d);
             }
-            idct_block(&c.data[(size_t)(my * c.v + by) * 8 * c.w2 + (size_t)(mx * c.h + bx) * 8], c.w2, block);
-        }
-        if (--todo <= 0) {  // restart marker: realign, reset predictors
-            br.reset();
-            const uint8_t *q = br.p;
-            while (q + 1 < br.end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) q++;
-            if (q + 1 < br.end) br.p = q + 2; else br.p = br.end;
-            for (auto &c : comp) c.dc_pred = 0;
-            todo = restart_interval;
-        }
-    }
     // ---- upsample + colour conversion, one output row at a time
     std::vector<uint8_t> out((size_t)width * height * 3);
+    if (grey) grey->resize((size_t)width * height);
     const int nc = (int)comp.size();
     const bool is_rgb = nc == 3 && ((comp[0].id == 'R' && comp[1].id == 'G' && comp[2].id == 'B') || (app14_transform == 0 && !jfif));
     struct Res { int hs, vs, ystep, w_lores, ypos; const uint8_t *line0, *line1; std::vector<uint8_t> buf; } res[3];
@@ -261,6 +362,11 @@ std::vector<uint8_t> decode_jpeg_rgb8(const std::vector<uint8_t> &file, int &wid
             if (++r.ystep >= r.vs) { r.ystep = 0; r.line0 = r.line1; if (++r.ypos < comp_rows[k]) r.line1 += comp[k].w2; }
         }
         uint8_t *o = &out[(size_t)j * width * 3];
+        if (grey) {
+            uint8_t *gq = grey->data() + (size_t)j * width;
+            if (nc == 3 && is_rgb) for (int i = 0; i < width; i++) gq[i] = (uint8_t)((row[0][i] * 77 + row[1][i] * 150 + 29 * row[2][i]) >> 8);
+            else memcpy(gq, row[0], (size_t)width);
+        }
         if (nc == 1) { for (int i = 0; i < width; i++) { o[3 * i] = o[3 * i + 1] = o[3 * i + 2] = row[0][i]; } }
         else if (is_rgb) { for (int i = 0; i < width; i++) { o[3 * i] = row[0][i]; o[3 * i + 1] = row[1][i]; o[3 * i + 2] = row[2][i]; } }
         else {

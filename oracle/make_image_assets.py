@@ -484,6 +484,24 @@ def main():
     write_pic("split_channels.pic", prgba, [(1, 0x80), (2, 0x60)], rng)
     wide = np.zeros((5, 400, 4), np.int64); wide[..., 0] = 7; wide[2, 100:, 1] = 200; wide[..., 2] = (np.arange(400) // 150) * 90
     write_pic("wide_long_runs.pic", wide, [(2, 0xE0)], rng)
+    # ---- JPEG: baseline and progressive files written by Pillow's libjpeg (this script runs in the authoring container only; the files
+    # are committed): chroma subsampling 4:2:0 / 4:2:2 / 4:4:4, grey, restart intervals, optimised Huffman tables; progressive files
+    # carry libjpeg's default scan script (interleaved DC, per-component AC bands, successive-approximation refinement scans)
+    from PIL import Image
+    def photo(w, h):
+        y, x = np.mgrid[0:h, 0:w]
+        base = np.stack([128 + 100 * np.sin(x / 5.0) * np.cos(y / 7.0), 128 + 90 * np.cos((x + y) / 9.0), 40 + 2.5 * x + 1.5 * y], -1)
+        return np.clip(base + rng.normal(0, 18, (h, w, 3)), 0, 255).astype(np.uint8)
+    small, large = photo(W, H), photo(83, 61)
+    Image.fromarray(small).save(os.path.join(OUT, "base_420.jpg"), quality=75)
+    Image.fromarray(large).save(os.path.join(OUT, "base_444_restart.jpg"), quality=90, subsampling=0, restart_marker_blocks=3)
+    Image.fromarray(small[..., 1]).save(os.path.join(OUT, "base_grey_optimized.jpg"), quality=60, optimize=True)
+    Image.fromarray(small).save(os.path.join(OUT, "prog_420.jpg"), quality=75, progressive=True)
+    Image.fromarray(small).save(os.path.join(OUT, "prog_422.jpg"), quality=85, subsampling=1, progressive=True)
+    Image.fromarray(large).save(os.path.join(OUT, "prog_444.jpg"), quality=92, subsampling=0, progressive=True)
+    Image.fromarray(large[..., 0]).save(os.path.join(OUT, "prog_grey.jpg"), quality=70, progressive=True)
+    Image.fromarray(large).save(os.path.join(OUT, "prog_420_restart.jpg"), quality=80, progressive=True, restart_marker_blocks=2)
+    Image.fromarray(photo(8, 8)).save(os.path.join(OUT, "prog_one_block.jpg"), quality=95, progressive=True)
     print("wrote", len(os.listdir(OUT)), "files to", OUT)
 
 
