@@ -8,6 +8,7 @@
 //   * 2x2 chroma upsampling uses the triangle filter  (3*near + far) per axis: (3*t_i + t_{i±1} + 8) >> 4;
 //   * YCbCr -> RGB in 20-bit fixed point with the BT.601 constants quantised to 12 bits.
 // Progressive files collect their coefficients over all scans (DC / AC bands, successive approximation) and go through the same transform.
+// Four-component files follow the Adobe marker: CMYK (transform 0), YCCK (2), else the fourth component is ignored.
 // Arithmetic-coded / lossless / hierarchical / 12-bit files are rejected with LJ_ERR_UNSUPPORTED (the reference's loader refuses them too).
 #include "host_scene.h"
 #include <cstring>
@@ -288,7 +289,7 @@ std::vector<uint8_t> decode_jpeg_rgb8(const std::vector<uint8_t> &file, int &wid
             if (file[seg] != 8) throw LjError(LJ_ERR_UNSUPPORTED, "JPEG " + name + ": only 8-bit samples are supported");
             height = rd16(seg + 1); width = rd16(seg + 3);
             int nc = file[seg + 5];
-            if (width <= 0 || height <= 0 || (nc != 1 && nc != 3)) throw LjError(LJ_ERR_UNSUPPORTED, "JPEG " + name + ": unsupported component count");
+            if (width <= 0 || height <= 0 || (nc != 1 && nc != 3 && nc != 4)) throw LjError(LJ_ERR_UNSUPPORTED, "JPEG " + name + ": unsupported component count");
             comp.resize(nc);
             for (int i = 0; i < nc; i++) {
                 comp[i].id = file[seg + 6 + 3 * i]; comp[i].h = file[seg + 7 + 3 * i] >> 4; comp[i].v = file[seg + 7 + 3 * i] & 15; comp[i].tq = file[seg + 8 + 3 * i];
@@ -345,39 +346,47 @@ std::vector<uint8_t> decode_jpeg_rgb8(const std::vector<uint8_t> &file, int &wid
     if (grey) grey->resize((size_t)width * height);
     const int nc = (int)comp.size();
     const bool is_rgb = nc == 3 && ((comp[0].id == 'R' && comp[1].id == 'G' && comp[2].id == 'B') || (app14_transform == 0 && !jfif));
-    struct Res { int hs, vs, ystep, w_lores, ypos; const uint8_t *line0, *line1; std::vector<uint8_t> buf; } res[3];
+    struct Res { int hs, vs, ystep, w_lores, ypos, rows; const uint8_t *line0, *line1; std::vector<uint8_t> buf; } res[4];
     for (int k = 0; k < nc; k++) {
         res[k].hs = hmax / comp[k].h; res[k].vs = vmax / comp[k].v; res[k].ystep = res[k].vs >> 1;
-        res[k].w_lores = (width + res[k].hs - 1) / res[k].hs; res[k].ypos = 0;
+        res[k].w_lores = (width + res[k].hs - 1) / res[k].hs; res[k].ypos = 0; res[k].rows = (height * comp[k].v + vmax - 1) / vmax;
         res[k].line0 = res[k].line1 = comp[k].data.data(); res[k].buf.resize((size_t)width + 8);
     }
-    const int comp_rows[3] = {nc > 0 ? (height * comp[0].v + vmax - 1) / vmax : 0, nc > 1 ? (height * comp[1].v + vmax - 1) / vmax : 0, nc > 2 ? (height * comp[2].v + vmax - 1) / vmax : 0};
+    auto ycc = [](int y, int cb_, int cr_, uint8_t *o) {   // BT.601 in 20-bit fixed point, the constants quantised to 12 bits
+        int y_fixed = (y << 20) + (1 << 19);
+        int cr = cr_ - 128, cb = cb_ - 128;
+        int r = y_fixed + cr * fixed12(1.40200f);
+        int g = y_fixed + (cr * -fixed12(0.71414f)) + ((cb * -fixed12(0.34414f)) & 0xffff0000);
+        int b = y_fixed + cb * fixed12(1.77200f);
+        o[0] = clamp8(r >> 20); o[1] = clamp8(g >> 20); o[2] = clamp8(b >> 20);
+    };
+    auto mul8 = [](int x, int y) { const unsigned t = (unsigned)(x * y + 128); return (uint8_t)((t + (t >> 8)) >> 8); };   // x * y / 255, rounded
+    auto luma = [](int r, int g, int b) { return (uint8_t)((r * 77 + g * 150 + 29 * b) >> 8); };
     for (int j = 0; j < height; j++) {
-        const uint8_t *row[3];
+        const uint8_t *row[4];
         for (int k = 0; k < nc; k++) {
             Res &r = res[k];
             bool y_bot = r.ystep >= (r.vs >> 1);
             resample_row(r.buf.data(), y_bot ? r.line1 : r.line0, y_bot ? r.line0 : r.line1, r.w_lores, r.hs, r.vs);
             row[k] = r.buf.data();
-            if (++r.ystep >= r.vs) { r.ystep = 0; r.line0 = r.line1; if (++r.ypos < comp_rows[k]) r.line1 += comp[k].w2; }
+            if (++r.ystep >= r.vs) { r.ystep = 0; r.line0 = r.line1; if (++r.ypos < r.rows) r.line1 += comp[k].w2; }
         }
         uint8_t *o = &out[(size_t)j * width * 3];
         if (grey) {
             uint8_t *gq = grey->data() + (size_t)j * width;
-            if (nc == 3 && is_rgb) for (int i = 0; i < width; i++) gq[i] = (uint8_t)((row[0][i] * 77 + row[1][i] * 150 + 29 * row[2][i]) >> 8);
+            if (nc == 3 && is_rgb) for (int i = 0; i < width; i++) gq[i] = luma(row[0][i], row[1][i], row[2][i]);
+            else if (nc == 4 && app14_transform == 0) for (int i = 0; i < width; i++) gq[i] = luma(mul8(row[0][i], row[3][i]), mul8(row[1][i], row[3][i]), mul8(row[2][i], row[3][i]));
+            else if (nc == 4 && app14_transform == 2) for (int i = 0; i < width; i++) gq[i] = mul8(255 - row[0][i], row[3][i]);
             else memcpy(gq, row[0], (size_t)width);
         }
         if (nc == 1) { for (int i = 0; i < width; i++) { o[3 * i] = o[3 * i + 1] = o[3 * i + 2] = row[0][i]; } }
         else if (is_rgb) { for (int i = 0; i < width; i++) { o[3 * i] = row[0][i]; o[3 * i + 1] = row[1][i]; o[3 * i + 2] = row[2][i]; } }
-        else {
-            for (int i = 0; i < width; i++) {
-                int y_fixed = (row[0][i] << 20) + (1 << 19);
-                int cr = row[2][i] - 128, cb = row[1][i] - 128;
-                int r = y_fixed + cr * fixed12(1.40200f);
-                int g = y_fixed + (cr * -fixed12(0.71414f)) + ((cb * -fixed12(0.34414f)) & 0xffff0000);
-                int b = y_fixed + cb * fixed12(1.77200f);
-                o[3 * i] = clamp8(r >> 20); o[3 * i + 1] = clamp8(g >> 20); o[3 * i + 2] = clamp8(b >> 20);
-            }
+        else if (nc == 4 && app14_transform == 0) {   // Adobe CMYK (stored inverted): each ink times black
+            for (int i = 0; i < width; i++) for (int c = 0; c < 3; c++) o[3 * i + c] = mul8(row[c][i], row[3][i]);
+        } else {
+            for (int i = 0; i < width; i++) ycc(row[0][i], row[1][i], row[2][i], o + 3 * i);
+            if (nc == 4 && app14_transform == 2)   // Adobe YCCK
+                for (int i = 0; i < width; i++) for (int c = 0; c < 3; c++) o[3 * i + c] = mul8(255 - o[3 * i + c], row[3][i]);
         }
     }
     return out;

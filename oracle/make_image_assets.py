@@ -502,6 +502,9 @@ def main():
     Image.fromarray(large[..., 0]).save(os.path.join(OUT, "prog_grey.jpg"), quality=70, progressive=True)
     Image.fromarray(large).save(os.path.join(OUT, "prog_420_restart.jpg"), quality=80, progressive=True, restart_marker_blocks=2)
     Image.fromarray(photo(8, 8)).save(os.path.join(OUT, "prog_one_block.jpg"), quality=95, progressive=True)
+    cmyk = np.concatenate([255 - small, rng.integers(120, 256, (H, W, 1)).astype(np.uint8)], -1)
+    Image.fromarray(cmyk, "CMYK").save(os.path.join(OUT, "base_cmyk.jpg"), quality=85)
+    Image.fromarray(cmyk, "CMYK").save(os.path.join(OUT, "prog_cmyk.jpg"), quality=85, progressive=True)
     print("wrote", len(os.listdir(OUT)), "files to", OUT)
 
 

@@ -278,7 +278,7 @@ def _fnv1a64(a):
 
 def test_every_image_format_the_reference_reads_decodes_to_the_same_texels():
     """imread3 / imread1 hand .jpg, .png, .hdr, .tga, .bmp, .psd, .gif and .pic files to stb_image and .exr files to tinyexr (image.cpp:28-133).  tests/assets/images/ holds small files: baseline and
-    progressive JPEG (4:2:0 / 4:2:2 / 4:4:4 / grey, restart intervals, optimised tables, libjpeg's full progressive scan script; one channel
+    progressive JPEG (4:2:0 / 4:2:2 / 4:4:4 / grey, restart intervals, optimised tables, libjpeg's full progressive scan script, Adobe CMYK; one channel
     of a YCbCr file is its Y plane), every PNG colour type / bit depth / filter type, Adam7, palettes with tRNS, Radiance HDR in its three encodings, every TGA image type
     (colour-mapped, true colour, grey; raw and run-length) x pixel / palette depth x origin, and BMP files of every header size, palette
     depth, 16 / 24 / 32-bit pixel layout and bit-field mask the reference's loader accepts, PSD files (raw / PackBits planes, 8 / 16 bits, an alpha plane that un-mattes the colours), GIF files (first frame: global / local palettes,
@@ -288,7 +288,7 @@ def test_every_image_format_the_reference_reads_decodes_to_the_same_texels():
     tests/golden/image_decode.json is what the reference's own loaders return for them (oracle/decode_with_reference.cpp).  Our decoders
     (jpeg_decode.cpp, png_decode.cpp, tga_bmp_decode.cpp, exr_decode.cpp) must return the same floats, bit for bit."""
     g = golden("image_decode")["files"]
-    assert len(g) >= 82 and {"base_420.jpg", "base_444_restart.jpg", "base_grey_optimized.jpg", "prog_420.jpg", "prog_422.jpg", "prog_444.jpg", "prog_grey.jpg",
+    assert len(g) >= 84 and {"base_cmyk.jpg", "prog_cmyk.jpg","base_420.jpg", "base_444_restart.jpg", "base_grey_optimized.jpg", "prog_420.jpg", "prog_422.jpg", "prog_444.jpg", "prog_grey.jpg",
                              "prog_420_restart.jpg", "prog_one_block.jpg","rgb_mixed.pic", "rgba_raw_alpha_rle.pic", "split_channels.pic", "wide_long_runs.pic","pal256.gif", "pal16_interlaced_transparent.gif", "local32_inset_bg.gif", "pal2_inset_interlaced.gif", "big_table_reset.gif","rgb8_raw.psd", "rgb8_rle.psd", "rgba8_rle.psd", "rgba16_raw_5ch.psd", "grey_pair_rle.psd","tiled_half_none.exr", "tiled_float_zip.exr", "tiled_grey_zip.exr", "tiled_mipmap_zip.exr", "gray1.png", "rgb16_interlaced.png", "pal4.png", "graya16.png", "rle.hdr", "flat_wide.hdr", "narrow.hdr",
                              "rgb24_rle.tga", "rgb15_rle.tga", "graya16.tga", "pal16_16.tga", "pal8_15_start.tga", "gray8_rle.tga",
                              "rgb24_core.bmp", "rgb32_fields_v3.bmp", "rgb16_odd_fields.bmp", "pal1.bmp", "pal4_gap.bmp", "rgb16_v4_4444.bmp"} <= set(g)
