@@ -269,6 +269,7 @@ HostImage decode_exr_rgb(const std::vector<uint8_t> &file, const std::string &na
     }
     (void)line_order;   // blocks carry their own y coordinate
     if (chans.empty() || x1 < x0 || y1 < y0) throw LjError(LJ_ERR_PARSE, "EXR header lacks channels or a data window: " + name);
+    check_image_size((long long)x1 - x0 + 1, (long long)y1 - y0 + 1, file.size(), name);
     const int w = x1 - x0 + 1, h = y1 - y0 + 1;
     int block_lines;
     switch (compression) {

@@ -15,6 +15,13 @@ struct LjError : std::runtime_error {
     LjError(int c, const std::string &what) : std::runtime_error(what), code(c) {}
 };
 
+// A decoder's sanity check of the size a file header claims, before anything is allocated for it: at most 2^24 texels a side (the
+// reference loader's limit), 2^28 in all, and not more than a file of this length could possibly encode (no format packs 8192 texels a byte).
+inline void check_image_size(long long w, long long h, size_t file_bytes, const std::string &name) {
+    if (w <= 0 || h <= 0 || w > (1 << 24) || h > (1 << 24) || w * h > (1ll << 28) || (unsigned long long)(w * h) > (unsigned long long)file_bytes * 8192ull + 65536ull)
+        throw LjError(LJ_ERR_PARSE, "image size in the header does not fit the file (" + std::to_string(w) + " x " + std::to_string(h) + "): " + name);
+}
+
 struct HostImage {
     int width = 0, height = 0, channels = 0;
     std::vector<float> data;

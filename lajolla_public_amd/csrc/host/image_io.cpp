@@ -48,6 +48,7 @@ HostImage read_pfm(const std::string &filename) {
     f.get();  // the single whitespace byte that ends the header
     int ch = magic == "PF" ? 3 : (magic == "Pf" ? 1 : 0);
     if (!f || ch == 0 || w <= 0 || h <= 0 || scale == 0) throw LjError(LJ_ERR_PARSE, "malformed PFM header: " + filename);
+    { const std::streampos at = f.tellg(); f.seekg(0, std::ios::end); const std::streampos end = f.tellg(); f.seekg(at); check_image_size(w, h, (size_t)end, filename); }
     HostImage img; img.width = w; img.height = h; img.channels = ch;
     img.data.resize((size_t)w * h * ch);
     std::vector<float> row((size_t)w * ch);

@@ -64,15 +64,30 @@ inline int extend(int v, int n) { return (n && v < (1 << (n - 1))) ? v - (1 << n
 inline uint8_t clamp8(int x) { return (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x)); }
 inline int f2f(double x) { return (int)(x * 4096 + 0.5); }
 
+// 32-bit two's-complement arithmetic that wraps (a damaged file can hold coefficients no encoder would write; their transform must stay
+// defined behaviour — for the values of a valid file nothing ever wraps, so results are unchanged)
+inline int wadd(int a, int b) { return (int)((uint32_t)a + (uint32_t)b); }
+inline int wmul(int a, int b) { return (int)((uint32_t)a * (uint32_t)b); }
+struct W {
+    int v;
+    W() : v(0) {}
+    W(int x) : v(x) {}
+    W &operator+=(W b) { v = wadd(v, b.v); return *this; }
+};
+inline W operator+(W a, W b) { return W(wadd(a.v, b.v)); }
+inline W operator-(W a, W b) { return W((int)((uint32_t)a.v - (uint32_t)b.v)); }
+inline W operator*(W a, W b) { return W(wmul(a.v, b.v)); }
+inline int operator>>(W a, int n) { return a.v >> n; }
+
 // one 1-D pass of the slow-integer IDCT on s0..s7; results are x0..x3 (even part) and t0..t3 (odd part), scaled by 2^12
 #define LJ_IDCT_1D(s0, s1, s2, s3, s4, s5, s6, s7)                                                 \
-    int t0, t1, t2, t3, p1, p2, p3, p4, p5, x0, x1, x2, x3;                                       \
-    p2 = s2; p3 = s6;                                                                              \
+    W t0, t1, t2, t3, p1, p2, p3, p4, p5, x0, x1, x2, x3;                                         \
+    p2 = W(s2); p3 = W(s6);                                                                        \
     p1 = (p2 + p3) * f2f(0.5411961f); t2 = p1 + p3 * f2f(-1.847759065f); t3 = p1 + p2 * f2f(0.765366865f); \
-    p2 = s0; p3 = s4;                                                                              \
+    p2 = W(s0); p3 = W(s4);                                                                        \
     t0 = (p2 + p3) * 4096; t1 = (p2 - p3) * 4096;                                                  \
     x0 = t0 + t3; x3 = t0 - t3; x1 = t1 + t2; x2 = t1 - t2;                                        \
-    t0 = s7; t1 = s5; t2 = s3; t3 = s1;                                                            \
+    t0 = W(s7); t1 = W(s5); t2 = W(s3); t3 = W(s1);                                                \
     p3 = t0 + t2; p4 = t1 + t3; p1 = t0 + t3; p2 = t1 + t2;                                        \
     p5 = (p3 + p4) * f2f(1.175875602f);                                                            \
     t0 = t0 * f2f(0.298631336f); t1 = t1 * f2f(2.053119869f); t2 = t2 * f2f(3.072711026f); t3 = t3 * f2f(1.501321110f); \
@@ -92,7 +107,7 @@ void idct_block(uint8_t *out, int stride, const short d[64]) {
     for (int i = 0; i < 8; i++) {  // rows; 2^12 * 2^2 * 2^3 = 2^17 to remove, round, and level-shift by +128
         const int *v = val + 8 * i; uint8_t *o = out + (size_t)stride * i;
         LJ_IDCT_1D(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7])
-        const int bias = 65536 + (128 << 17);
+        const W bias(65536 + (128 << 17));
         x0 += bias; x1 += bias; x2 += bias; x3 += bias;
         o[0] = clamp8((x0 + t3) >> 17); o[7] = clamp8((x0 - t3) >> 17); o[1] = clamp8((x1 + t2) >> 17); o[6] = clamp8((x1 - t2) >> 17);
         o[2] = clamp8((x2 + t1) >> 17); o[5] = clamp8((x2 - t1) >> 17); o[3] = clamp8((x3 + t0) >> 17); o[4] = clamp8((x3 - t0) >> 17);
@@ -165,15 +180,15 @@ std::vector<uint8_t> decode_jpeg_rgb8(const std::vector<uint8_t> &file, int &wid
                 int t = decode_symbol(br, hdc[c.td]);
                 if (t > 11) throw bad("bad DC magnitude");
                 int diff = t ? extend(br.bits(t), t) : 0;
-                c.dc_pred += diff;
-                block[0] = (short)(c.dc_pred * qt[c.tq][0]);
+                c.dc_pred = wadd(c.dc_pred, diff);
+                block[0] = (short)wmul(c.dc_pred, qt[c.tq][0]);
                 for (int k = 1; k < 64;) {
                     int rs = decode_symbol(br, hac[c.ta]);
                     int r = rs >> 4, sz = rs & 15;
                     if (sz == 0) { if (r != 15) break; k += 16; continue; }
                     k += r;
                     if (k > 63) throw bad("AC index out of range");
-                    block[kZigzag[k]] = (short)(extend(br.bits(sz), sz) * qt[c.tq][kZigzag[k]]);
+                    block[kZigzag[k]] = (short)wmul(extend(br.bits(sz), sz), qt[c.tq][kZigzag[k]]);
                     k++;
                 }
                 idct_block(&c.data[(size_t)by * 8 * c.w2 + (size_t)bx * 8], c.w2, block);
@@ -185,8 +200,8 @@ std::vector<uint8_t> decode_jpeg_rgb8(const std::vector<uint8_t> &file, int &wid
                 if (Ah == 0) {
                     int t = decode_symbol(br, hdc[c.td]);
                     if (t > 15) throw bad("bad DC magnitude");
-                    c.dc_pred += t ? extend(br.bits(t), t) : 0;
-                    d[0] = (short)(c.dc_pred * (1 << Al));
+                    c.dc_pred = wadd(c.dc_pred, t ? extend(br.bits(t), t) : 0);
+                    d[0] = (short)wmul(c.dc_pred, 1 << Al);
                 } else if (br.bit()) d[0] = (short)(d[0] + (1 << Al));
                 return;
             }
@@ -202,7 +217,7 @@ std::vector<uint8_t> decode_jpeg_rgb8(const std::vector<uint8_t> &file, int &wid
                     } else {
                         k += r;
                         if (k > 63) throw bad("AC index out of range");
-                        d[kZigzag[k++]] = (short)(extend(br.bits(sz), sz) * (1 << Al));
+                        d[kZigzag[k++]] = (short)wmul(extend(br.bits(sz), sz), 1 << Al);
                     }
                 } while (k <= Se);
                 return;
@@ -290,6 +305,7 @@ std::vector<uint8_t> decode_jpeg_rgb8(const std::vector<uint8_t> &file, int &wid
             height = rd16(seg + 1); width = rd16(seg + 3);
             int nc = file[seg + 5];
             if (width <= 0 || height <= 0 || (nc != 1 && nc != 3 && nc != 4)) throw LjError(LJ_ERR_UNSUPPORTED, "JPEG " + name + ": unsupported component count");
+            check_image_size(width, height, n, name);
             comp.resize(nc);
             for (int i = 0; i < nc; i++) {
                 comp[i].id = file[seg + 6 + 3 * i]; comp[i].h = file[seg + 7 + 3 * i] >> 4; comp[i].v = file[seg + 7 + 3 * i] & 15; comp[i].tq = file[seg + 8 + 3 * i];
@@ -338,7 +354,7 @@ std::vector<uint8_t> decode_jpeg_rgb8(const std::vector<uint8_t> &file, int &wid
         for (auto &c : comp)
             for (int by = 0; by < c.h2 / 8; by++) for (int bx = 0; bx < c.w2 / 8; bx++) {
                 short *d = &c.coeff[((size_t)by * (c.w2 / 8) + bx) * 64];
-                for (int i = 0; i < 64; i++) d[i] = (short)(d[i] * qt[c.tq][i]);
+                for (int i = 0; i < 64; i++) d[i] = (short)wmul(d[i], qt[c.tq][i]);
                 idct_block(&c.data[(size_t)by * 8 * c.w2 + (size_t)bx * 8], c.w2, d);
             }
     // ---- upsample + colour conversion, one output row at a time

@@ -63,7 +63,7 @@ void decode_png(const std::vector<uint8_t> &file, const std::string &name, int &
         if (type == "IHDR") {
             if (len != 13) throw LjError(LJ_ERR_PARSE, "bad IHDR: " + name);
             width = (int)be32(d); height = (int)be32(d + 4); depth = d[8]; ctype = d[9]; interlace = d[12];
-            if (width <= 0 || height <= 0 || (size_t)width * height > ((size_t)1 << 28)) throw LjError(LJ_ERR_PARSE, "bad PNG size: " + name);
+            check_image_size(width, height, file.size(), name);
             if (d[10] != 0 || d[11] != 0 || interlace > 1) throw LjError(LJ_ERR_PARSE, "bad PNG compression / filter / interlace method: " + name);
             const bool ok = (ctype == 0 && (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)) || (ctype == 3 && (depth == 1 || depth == 2 || depth == 4 || depth == 8)) ||
                             ((ctype == 2 || ctype == 4 || ctype == 6) && (depth == 8 || depth == 16));
@@ -175,6 +175,7 @@ HostImage read_hdr(const std::vector<uint8_t> &file, const std::string &name, in
     const std::string res = line();
     int w = 0, h = 0;
     if (sscanf(res.c_str(), "-Y %d +X %d", &h, &w) != 2 || w <= 0 || h <= 0) throw LjError(LJ_ERR_UNSUPPORTED, "HDR data layout other than '-Y h +X w': " + name);
+    check_image_size(w, h, file.size(), name);
     HostImage img; img.width = w; img.height = h; img.channels = channels == 1 ? 1 : 3;
     img.data.assign((size_t)w * h * img.channels, 0.0f);
     auto need = [&](size_t n) { if (p + n > file.size()) throw LjError(LJ_ERR_PARSE, "truncated HDR pixel data: " + name); };

@@ -67,6 +67,7 @@ HostImage read_tga(const std::vector<uint8_t> &file, const std::string &name, in
     if (cmap_type == 1) ok = ok && (type == 1 || type == 9) && depth_ok(pal_bits) && (bpp == 8 || bpp == 16);
     else ok = ok && (type == 2 || type == 3 || type == 10 || type == 11);
     if (!ok) throw LjError(LJ_ERR_PARSE, "not a TGA file this build (or the reference's loader) decodes: " + name);
+    check_image_size(w, h, file.size(), name);
     const bool rle = type >= 8;
     if (rle) type -= 8;
     const bool indexed = cmap_type == 1, bottom_up = ((desc >> 5) & 1) == 0;
@@ -152,7 +153,7 @@ HostImage read_bmp(const std::vector<uint8_t> &file, const std::string &name, in
     }
     const bool bottom_up = hs > 0;
     const int h = hs < 0 ? -hs : hs;
-    if (w <= 0 || h <= 0 || w > (1 << 24) || h > (1 << 24)) throw LjError(LJ_ERR_PARSE, "corrupt BMP (size): " + name);
+    check_image_size(w, h, file.size(), name);
     long long psize = 0;
     if (hsz == 12) { if (bpp < 24) psize = (offset - extra - 24) / 3; }
     else if (bpp < 16) psize = (offset - extra - hsz) >> 2;
@@ -228,7 +229,7 @@ HostImage read_psd(const std::vector<uint8_t> &file, const std::string &name, in
     const int n_ch = (int)be16();
     if (n_ch > 16) throw LjError(LJ_ERR_UNSUPPORTED, "PSD with more than 16 channels: " + name);
     const long long h = (int32_t)be32(), w = (int32_t)be32();
-    if (w <= 0 || h <= 0 || w > (1 << 24) || h > (1 << 24)) throw LjError(LJ_ERR_PARSE, "corrupt PSD (size): " + name);
+    check_image_size(w, h, file.size(), name);
     const int depth = (int)be16();
     if (depth != 8 && depth != 16) throw LjError(LJ_ERR_UNSUPPORTED, "PSD bit depth is not 8 or 16: " + name);
     if (be16() != 3) throw LjError(LJ_ERR_UNSUPPORTED, "PSD is not in RGB colour mode: " + name);
@@ -279,7 +280,7 @@ HostImage read_gif(const std::vector<uint8_t> &file, const std::string &name, in
     if ((ver != '7' && ver != '9') || r.u8() != 'a') throw LjError(LJ_ERR_PARSE, "not a GIF file: " + name);
     const int W = (int)r.u16(), H = (int)r.u16(), flags = r.u8(), bgindex = r.u8();
     r.u8();
-    if (W <= 0 || H <= 0) throw LjError(LJ_ERR_PARSE, "corrupt GIF (size): " + name);
+    check_image_size(W, H, file.size(), name);
     uint8_t gpal[256][4] = {}, lpal[256][4] = {};   // entries as R, G, B, alpha
     auto read_palette = [&](uint8_t pal[256][4], int n, int transparent) {
         for (int i = 0; i < n; i++) { pal[i][0] = r.u8(); pal[i][1] = r.u8(); pal[i][2] = r.u8(); pal[i][3] = transparent == i ? 0 : 255; }
@@ -377,7 +378,7 @@ HostImage read_pic(const std::vector<uint8_t> &file, const std::string &name, in
     auto be16 = [&]() { const uint32_t a = r.u8(); return (int)((a << 8) | r.u8()); };
     const int w = be16(), h = be16();
     r.skip(8);   // ratio, fields, pad
-    if (w <= 0 || h <= 0) throw LjError(LJ_ERR_PARSE, "corrupt PIC (size): " + name);
+    check_image_size(w, h, file.size(), name);
     struct Packet { int type, channel; };
     std::vector<Packet> packets;
     for (bool chained = true; chained;) {

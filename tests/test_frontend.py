@@ -313,3 +313,24 @@ def test_unsupported_and_broken_images_fail_loudly(tmp_path):
     with pytest.raises(lj.LajollaError) as e:
         lj.read_image(str(tmp_path / "missing.png"), 3)
     assert e.value.code == _abi.LJ_ERR_IO
+
+
+def test_image_headers_that_do_not_fit_their_file_are_refused(tmp_path):
+    """A header may claim any size; nothing is allocated for one the file could not possibly hold (found by tools/fuzz_decoders.sh: a damaged
+    BMP asked for 1.5 TB)."""
+    src = open(os.path.join(ROOT, "tests", "assets", "images", "rgb24.bmp"), "rb").read()
+    big = bytearray(src)
+    big[18:22] = (1 << 23).to_bytes(4, "little")     # width
+    big[22:26] = (1 << 23).to_bytes(4, "little")     # height
+    p = tmp_path / "huge.bmp"
+    p.write_bytes(bytes(big))
+    with pytest.raises(lj.LajollaError) as e:
+        lj.read_image(str(p), 3)
+    assert e.value.code == _abi.LJ_ERR_PARSE
+    tga = bytearray(open(os.path.join(ROOT, "tests", "assets", "images", "rgb24_rle.tga"), "rb").read())
+    tga[12:16] = b"\xff\xff\xff\xff"                  # 65535 x 65535 run-length TGA in a 2 KB file
+    p = tmp_path / "huge.tga"
+    p.write_bytes(bytes(tga))
+    with pytest.raises(lj.LajollaError) as e:
+        lj.read_image(str(p), 3)
+    assert e.value.code == _abi.LJ_ERR_PARSE
