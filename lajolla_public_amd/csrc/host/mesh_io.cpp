@@ -164,9 +164,12 @@ LjShape load_serialized_mesh(HostScene &hs, const std::string &filename, int sha
     if (shape_index > 0) {  // end-of-file dictionary (load_serialized.cpp:103-121)
         uint32_t count = rd32(file.size() - 4);
         if ((uint32_t)shape_index >= count) throw LjError(LJ_ERR_PARSE, "shapeIndex out of range in " + filename);
-        if (version == 4) offset = (size_t)rd64(file.size() - 8 * (size_t)(count - shape_index) - 4);
-        else offset = (size_t)rd32(file.size() - 4 * (size_t)(count - shape_index + 1));
-        offset += 4;
+        // (the dictionary — one offset per sub-mesh, then the count — has to lie inside the file)
+        const unsigned long long back = version == 4 ? 8ull * (count - (uint32_t)shape_index) + 4ull : 4ull * ((unsigned long long)(count - (uint32_t)shape_index) + 1ull);
+        if (back + 4ull > file.size()) throw LjError(LJ_ERR_PARSE, "sub-mesh dictionary reaches outside the file: " + filename);
+        const unsigned long long sub = version == 4 ? rd64(file.size() - (size_t)back) : rd32(file.size() - (size_t)back);
+        if (sub >= file.size()) throw LjError(LJ_ERR_PARSE, "bad sub-mesh offset in " + filename);
+        offset = (size_t)sub + 4;
     }
     if (offset >= file.size()) throw LjError(LJ_ERR_PARSE, "bad sub-mesh offset in " + filename);
 
@@ -187,7 +190,9 @@ LjShape load_serialized_mesh(HostScene &hs, const std::string &filename, int sha
     if (version == 4) { char c; do { zread(&c, 1); } while (c != '\0'); }
     uint64_t vertex_count, triangle_count;
     zread(&vertex_count, 8); zread(&triangle_count, 8);
-    if (vertex_count > (1ull << 31) || triangle_count > (1ull << 31)) { inflateEnd(&zs); throw LjError(LJ_ERR_PARSE, "implausible mesh size in " + filename); }
+    // (deflate expands at most ~1030-fold: counts the rest of the file could not hold are a damaged header, not a reason to allocate gigabytes)
+    const unsigned long long can_hold = (unsigned long long)(file.size() - offset) * 1100ull + 4096ull;
+    if (vertex_count > (1ull << 31) || triangle_count > (1ull << 31) || vertex_count * 12ull > can_hold || triangle_count * 12ull > can_hold) { inflateEnd(&zs); throw LjError(LJ_ERR_PARSE, "implausible mesh size in " + filename); }
     bool dbl = flags & DoublePrecision;
     auto read_reals = [&](size_t n) {
         std::vector<double> out(n);
@@ -237,6 +242,12 @@ void load_grid_volume(const std::string &filename, LjVolume &v, std::vector<floa
     f.read((char *)box, 24);
     if (!f || res[0] <= 0 || res[1] <= 0 || res[2] <= 0) throw LjError(LJ_ERR_PARSE, "malformed volume header: " + filename);
     const size_t n = (size_t)res[0] * res[1] * res[2];
+    {   // a damaged header must not make us allocate terabytes: the grid may be larger than the file (missing voxels read as zero, below),
+        // but not out of all proportion to it
+        const std::streampos at = f.tellg(); f.seekg(0, std::ios::end); const unsigned long long bytes = (unsigned long long)f.tellg(); f.seekg(at);
+        if ((unsigned long long)res[0] * (unsigned long long)res[1] > (1ull << 40) || n > (1ull << 31) || (unsigned long long)n * channels * 4ull > std::max<unsigned long long>(64ull << 20, 64ull * bytes))
+            throw LjError(LJ_ERR_PARSE, "volume resolution in the header does not fit the file: " + filename);
+    }
     std::vector<float> raw(n * channels, 0.0f);
     f.read((char *)raw.data(), (std::streamsize)(raw.size() * 4));   // a short file leaves zeros, as the reference's read does
     v = LjVolume{};

@@ -334,3 +334,28 @@ def test_image_headers_that_do_not_fit_their_file_are_refused(tmp_path):
     with pytest.raises(lj.LajollaError) as e:
         lj.read_image(str(p), 3)
     assert e.value.code == _abi.LJ_ERR_PARSE
+
+
+def test_damaged_serialized_mesh_and_volume_headers_are_refused(tmp_path):
+    """Found by tools/fuzz_scenes.sh: a sub-mesh dictionary that points outside the file, and a grid volume whose header asks for more voxels
+    than the file could hold, have to be refused — not followed / allocated."""
+    import shutil
+    d = tmp_path / "matpreview"
+    shutil.copytree(os.path.join(ROOT, "scenes", "matpreview"), d)
+    ser = bytearray((d / "matpreview.serialized").read_bytes())
+    ser[-4:] = (0x7fffffff).to_bytes(4, "little")          # sub-mesh count: the dictionary would start far before the file
+    (d / "matpreview.serialized").write_bytes(bytes(ser))
+    with pytest.raises(lj.LajollaError) as e:
+        lj.parse_scene(str(d / "matpreview.xml"))
+    assert e.value.code == _abi.LJ_ERR_PARSE
+    v = tmp_path / "vol"
+    v.mkdir()
+    for f in ("hetvol.xml", "smoke.vol", "bounds.obj"):
+        if os.path.exists(os.path.join(ROOT, "scenes", "volpath_test", f)):
+            shutil.copy(os.path.join(ROOT, "scenes", "volpath_test", f), v / f)
+    vol = bytearray((v / "smoke.vol").read_bytes())
+    vol[8:20] = (30000).to_bytes(4, "little") * 3         # 2.7e13 voxels
+    (v / "smoke.vol").write_bytes(bytes(vol))
+    with pytest.raises(lj.LajollaError) as e:
+        lj.parse_scene(str(v / "hetvol.xml"))
+    assert e.value.code == _abi.LJ_ERR_PARSE
