@@ -96,6 +96,27 @@ FlatScene flatten_scene(const LjSceneDesc &d) {
     if (d.options.integrator < LJ_INTEGRATOR_DEPTH || d.options.integrator > LJ_INTEGRATOR_VOLPATH)
         throw LjError(LJ_ERR_UNSUPPORTED, "integrator id " + std::to_string(d.options.integrator) + " is not implemented");
     const bool volumetric = d.options.integrator == LJ_INTEGRATOR_VOLPATH;
+    // ---- numbers the kernels index memory with must be finite: a NaN in a camera matrix, a vertex or a light transform turns into NaN
+    // directions and from there into texel / table indices on the device (the reference has the same hole; a GPU fault is a worse failure)
+    {
+        auto finite = [](const double *v, size_t n) { for (size_t i = 0; i < n; i++) if (!std::isfinite(v[i])) return false; return true; };
+        if (!finite(d.camera.cam_to_world, 16) || !finite(d.camera.sample_to_cam, 16) || !std::isfinite(d.camera.filter_param))
+            throw LjError(LJ_ERR_INVALID_ARG, "camera: matrix or filter parameter is not finite");
+        if (d.camera.width <= 0 || d.camera.height <= 0 || (long long)d.camera.width * d.camera.height > (1ll << 28)) throw LjError(LJ_ERR_INVALID_ARG, "camera: bad film size");
+        if (d.n_vertices > 0 && (!d.positions || !finite(d.positions, (size_t)d.n_vertices * 3))) throw LjError(LJ_ERR_INVALID_ARG, "a vertex position is not finite");
+        for (int i = 0; i < d.n_shapes; i++) {
+            const LjShape &sh = d.shapes[i];
+            if (sh.kind == LJ_SHAPE_SPHERE && (!finite(sh.position, 3) || !std::isfinite(sh.radius))) throw LjError(LJ_ERR_INVALID_ARG, "sphere " + std::to_string(i) + ": centre or radius is not finite");
+            if (sh.kind != LJ_SHAPE_SPHERE && sh.n_vertices > 0) {
+                if (sh.first_vertex < 0 || sh.first_vertex + sh.n_vertices > d.n_vertices) throw LjError(LJ_ERR_INVALID_ARG, "shape " + std::to_string(i) + ": vertex range outside the pools");
+                if (sh.has_normals && d.normals && !finite(d.normals + 3 * sh.first_vertex, (size_t)sh.n_vertices * 3)) throw LjError(LJ_ERR_INVALID_ARG, "shape " + std::to_string(i) + ": a vertex normal is not finite");
+                if (sh.has_uvs && d.uvs && !finite(d.uvs + 2 * sh.first_vertex, (size_t)sh.n_vertices * 2)) throw LjError(LJ_ERR_INVALID_ARG, "shape " + std::to_string(i) + ": a texture coordinate is not finite");
+            }
+        }
+        for (int i = 0; i < d.n_lights; i++)
+            if (!finite(d.lights[i].intensity, 3) || !std::isfinite(d.lights[i].scale) || (d.lights[i].kind == LJ_LIGHT_ENVMAP && (!finite(d.lights[i].to_world, 16) || !finite(d.lights[i].to_local, 16))))
+                throw LjError(LJ_ERR_INVALID_ARG, "light " + std::to_string(i) + ": intensity, scale or transform is not finite");
+    }
     F.cam_medium = d.camera.medium_id; F.max_null_collisions = d.options.max_null_collisions; F.vol_path_version = d.options.vol_path_version;
     // ---- participating media (only the volumetric integrator looks at them)
     auto medium_ok = [&](int id) { return id >= -1 && id < d.n_media; };

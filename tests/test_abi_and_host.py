@@ -145,3 +145,22 @@ def test_driver_prints_the_usage_line_without_arguments(capsys):
     from lajolla_public_amd.__main__ import main
     assert main([]) == 0
     assert capsys.readouterr().out.startswith("[Usage]")
+
+
+def test_non_finite_scene_numbers_are_refused_at_flattening():
+    """A NaN in a camera matrix, a vertex or a light would become a NaN direction and, on the device, a texel / table index: flatten_scene
+    (what lj_scene_upload runs first) refuses such a description.  Checked through the host twin, which links the product's flatten.cpp."""
+    from helpers import Twin
+    for poke in ("vertex", "camera", "light"):
+        hs = lj.parse_scene(os.path.join(ROOT, "scenes", "cbox", "cbox.xml"))
+        d = hs.desc
+        if poke == "vertex":
+            d.positions[7] = float("nan")
+        elif poke == "camera":
+            d.camera.cam_to_world[3] = float("inf")
+        else:
+            d.lights[0].intensity[1] = float("nan")
+        with pytest.raises(RuntimeError) as e:
+            Twin(hs)
+        assert "finite" in str(e.value), poke
+    Twin(lj.parse_scene(os.path.join(ROOT, "scenes", "cbox", "cbox.xml")))
