@@ -465,7 +465,18 @@ int lj_scene_upload(lj_context *ctx, const LjSceneDesc *desc, lj_scene **out) {
         sc->flat = lj::flatten_scene(*desc);
         lj::FlatScene &F = sc->flat;
         hipStream_t s = ctx->stream;
-        upload(sc->nodes, F.nodes, s); upload(sc->leaf_prims, F.leaf_prims, s); upload(sc->prims, F.prims, s); upload(sc->spheres, F.spheres, s);
+        upload(sc->nodes, F.nodes, s);
+        // BVH8 nodes: 80 bytes each; LJ_TUNE_NODE8_STRIDE=128 lays them out one per 128-byte cache line (a node then never straddles two lines)
+        int node8_stride = (int)sizeof(ljd::DNode8);
+        if (const char *e = getenv("LJ_TUNE_NODE8_STRIDE")) node8_stride = atoi(e) >= 128 ? 128 : 80;
+        std::vector<unsigned char> nodes8_padded;
+        if (node8_stride == (int)sizeof(ljd::DNode8)) upload(sc->nodes8, F.nodes8, s);
+        else {
+            nodes8_padded.assign(F.nodes8.size() * (size_t)node8_stride, 0);
+            for (size_t i = 0; i < F.nodes8.size(); i++) memcpy(&nodes8_padded[i * (size_t)node8_stride], &F.nodes8[i], sizeof(ljd::DNode8));
+            upload(sc->nodes8, nodes8_padded, s);
+        }
+        upload(sc->leaf_prims, F.leaf_prims, s); upload(sc->prims, F.prims, s); upload(sc->spheres, F.spheres, s);
         upload(sc->materials, F.materials, s); upload(sc->lights, F.lights, s); upload(sc->light_cdf, F.light_cdf, s);
         upload(sc->light_tris, F.light_tris, s); upload(sc->light_tri_cdf, F.light_tri_cdf, s);
         upload(sc->images3, F.images3, s); upload(sc->images1, F.images1, s); upload(sc->texels, F.texels, s); upload(sc->env_tables, F.env_tables, s);
@@ -473,7 +484,7 @@ int lj_scene_upload(lj_context *ctx, const LjSceneDesc *desc, lj_scene **out) {
         upload(sc->scan_leaves, F.scan_leaves, s);
         HIP_CHECK(hipStreamSynchronize(s));
         ljd::DScene d = F.host_view();
-        d.nodes = (const ljd::DNode4 *)sc->nodes.p; d.leaf_prims = (const ljd::DPrim *)sc->leaf_prims.p; d.prims = (const ljd::DPrimShade *)sc->prims.p;
+        d.nodes = (const ljd::DNode4 *)sc->nodes.p; d.nodes8 = (const ljd::DNode8 *)sc->nodes8.p; d.node8_stride = node8_stride; d.leaf_prims = (const ljd::DPrim *)sc->leaf_prims.p; d.prims = (const ljd::DPrimShade *)sc->prims.p;
         d.spheres = (const ljd::DSphere *)sc->spheres.p; d.materials = (const ljd::DMaterial *)sc->materials.p; d.lights = (const ljd::DLight *)sc->lights.p;
         d.light_cdf = (const float *)sc->light_cdf.p; d.light_tris = (const ljd::DLightTri *)sc->light_tris.p; d.light_tri_cdf = (const float *)sc->light_tri_cdf.p;
         d.images3 = (const ljd::DImage *)sc->images3.p; d.images1 = (const ljd::DImage *)sc->images1.p; d.texels = (const float *)sc->texels.p; d.env_tables = (const float *)sc->env_tables.p;
@@ -486,7 +497,7 @@ int lj_scene_upload(lj_context *ctx, const LjSceneDesc *desc, lj_scene **out) {
         }
         if (F.bvh_depth > ljd::max_stack_depth())
             throw LjError(LJ_ERR_INTERNAL, "BVH depth " + std::to_string(F.bvh_depth) + " exceeds the traversal stack");
-        sc->ecfg = ljd::extend_config((int)F.nodes.size(), (int)F.leaf_prims.size(), F.bvh_depth, (int)F.n_spheres);
+        sc->ecfg = ljd::extend_config((int)F.nodes.size(), (int)F.leaf_prims.size(), F.bvh_depth, (int)F.n_spheres, (int)F.nodes8.size(), F.bvh8_depth);
         if (const char *e = getenv("LJ_TUNE_REFILL")) sc->ecfg.refill_min = (uint32_t)atoi(e);
         if (const char *e = getenv("LJ_TUNE_MINDESC")) sc->ecfg.min_descending = (uint32_t)atoi(e);
         sc->scfg = ljd::shade_config(F.prims.size(), F.materials.size(), F.lights.size(), F.light_tris.size(), F.light_tri_cdf.size());

@@ -17,7 +17,7 @@
 namespace ljd {
 ShadeConfig shade_config(size_t n_prims, size_t n_materials, size_t n_lights, size_t n_light_tris, size_t n_light_tri_cdf);
 int shade_variant(uint32_t kinds, bool textured, bool envmap, bool sphere_lights);
-ExtendConfig extend_config(int n_nodes, int n_prims, int bvh_depth, int n_spheres);
+ExtendConfig extend_config(int n_nodes, int n_prims, int bvh_depth, int n_spheres, int n_nodes8, int bvh8_depth);
 int max_stack_depth();
 void launch_extend(const DScene &sc, const DQueue &q, const DBlockState *blocks, uint32_t grid, uint32_t seg, uint32_t *work, const uint32_t *chunk_list, uint32_t parity, const ExtendConfig &cfg, int *spill, unsigned long long *stats, hipStream_t s);
 void launch_shade(const DScene &sc, const DPass &pass, const DQueue &q, DBlockState *blocks, uint32_t n_blocks, uint32_t seg, const ShadeConfig &cfg, uint32_t *work, uint32_t *chunk_list, uint32_t parity, uint32_t extend_waves, hipStream_t s);
@@ -76,7 +76,7 @@ struct lj_context {
 struct lj_scene {
     lj_context *ctx = nullptr;
     lj::FlatScene flat;  // host copy (tables for lj_scene_info; arrays already uploaded)
-    DevBuf nodes, leaf_prims, prims, spheres, materials, lights, light_cdf, light_tris, light_tri_cdf, images3, images1, texels, env_tables;
+    DevBuf nodes, nodes8, leaf_prims, prims, spheres, materials, lights, light_cdf, light_tris, light_tri_cdf, images3, images1, texels, env_tables;
     DevBuf media, volume_data, shape_media, scan_leaves;
     ljd::DScene dscene{};
     ljd::ExtendConfig ecfg{};

@@ -10,7 +10,11 @@ constexpr int kNumShadeVariants = 5;
 constexpr int kShadeVariantAll = kNumShadeVariants - 1;
 
 // LDS image of the extend kernel: stack levels, staged nodes / primitives, which instantiation
-struct ExtendConfig { int stack; int spill_levels; int lds_nodes; int lds_prims; int resident; int spheres; size_t smem; uint32_t refill_min, min_descending; };
+struct ExtendConfig {
+    int stack; int spill_levels; int lds_nodes; int lds_prims; int resident; int spheres; size_t smem; uint32_t refill_min, min_descending;
+    // trees beyond the LDS image: the BVH8 kernels (k_extend8); group-stack levels in LDS, staged nodes, bytes of that image
+    int wide; int stack8; int lds_nodes8; size_t smem8;
+};
 // LDS staging plan of the shade kernel (sizes rounded up to 16 bytes) and the feature-set instantiation (dshade.h)
 struct ShadeConfig { uint32_t prims_bytes, materials_bytes, lights_bytes, light_cdf_bytes, light_tris_bytes, light_tri_cdf_bytes, stage_prims; int variant; size_t smem; };
 

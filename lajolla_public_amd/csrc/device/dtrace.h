@@ -152,6 +152,91 @@ LJ_HD bool traverse(Mem &mem, const RayF &ray, HitRec &best) {
     return best.gprim >= 0;
 }
 
+// ---- BVH8 (DNode8): slab test of all eight children on the node's 8-bit grid, and the octant-ordered traversal.
+// plane = p + q * 2^(e-127); t = (plane - o) * i = q * (2^(e-127) * i) + (p * i - o * i): one conversion and one fma per plane.
+struct Ray8 {
+    float ix, iy, iz, oix, oiy, oiz;   // 1 / d and o / d
+    uint32_t oct;                      // bit k: the ray runs towards the low side of axis k
+};
+LJ_HD float grid_step(uint32_t biased_exponent) {   // 2^(e - 127), e in 1 .. 254
+    union { uint32_t u; float f; } c; c.u = biased_exponent << 23; return c.f;
+}
+LJ_HD float byte_f(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xffu); }   // v_cvt_f32_ubyte<k> on the device
+// w[0..19]: the node as twenty dwords.  Returns the slots (bit s = slot s) whose quantised box the ray segment [tnear, tfar] enters;
+// like box_test4 the exit distance is widened by 4 ulp, and an axis the ray does not move along (i = inf: every plane reads nan) drops out.
+LJ_HD uint32_t node8_hits(const uint32_t *w, const Ray8 &r, float tnear, float tfar) {
+    union { uint32_t u; float f; } px, py, pz; px.u = w[0]; py.u = w[1]; pz.u = w[2];
+    const float ax = grid_step(w[3] & 0xffu) * r.ix, ay = grid_step((w[3] >> 8) & 0xffu) * r.iy, az = grid_step((w[3] >> 16) & 0xffu) * r.iz;
+    const float bx = __builtin_fmaf(px.f, r.ix, -r.oix), by = __builtin_fmaf(py.f, r.iy, -r.oiy), bz = __builtin_fmaf(pz.f, r.iz, -r.oiz);
+    // dwords 8..19: qlo_x[0-3] qlo_x[4-7] qlo_y.. qlo_y.. | qlo_z qlo_z qhi_x qhi_x | qhi_y qhi_y qhi_z qhi_z
+    const bool nx = (r.oct & 1u) != 0u, ny = (r.oct & 2u) != 0u, nz = (r.oct & 4u) != 0u;
+    uint32_t hits = 0u;
+    for (int h = 0; h < 2; h++) {
+        const uint32_t lox = w[8 + h], loy = w[10 + h], loz = w[12 + h], hix = w[14 + h], hiy = w[16 + h], hiz = w[18 + h];
+        const uint32_t nearx = nx ? hix : lox, farx = nx ? lox : hix;
+        const uint32_t neary = ny ? hiy : loy, fary = ny ? loy : hiy;
+        const uint32_t nearz = nz ? hiz : loz, farz = nz ? loz : hiz;
+        for (int k = 0; k < 4; k++) {
+            const float t0 = fmaxf(fmaxf(__builtin_fmaf(byte_f(nearx, k), ax, bx), __builtin_fmaf(byte_f(neary, k), ay, by)), fmaxf(__builtin_fmaf(byte_f(nearz, k), az, bz), tnear));
+            const float t1 = fminf(fminf(__builtin_fmaf(byte_f(farx, k), ax, bx), __builtin_fmaf(byte_f(fary, k), ay, by)), fminf(__builtin_fmaf(byte_f(farz, k), az, bz), tfar));
+            hits |= (t0 <= t1 * 1.0000005f) ? (1u << (4 * h + k)) : 0u;
+        }
+    }
+    return hits;
+}
+// bit s of m moves to bit (s ^ oct): after this the lowest set bit is the slot the ray meets first
+LJ_HD uint32_t perm8(uint32_t m, uint32_t oct) {
+    uint32_t t = ((m & 0x55u) << 1) | ((m >> 1) & 0x55u); m = (oct & 1u) ? t : m;
+    t = ((m & 0x33u) << 2) | ((m >> 2) & 0x33u); m = (oct & 2u) ? t : m;
+    t = ((m & 0x0fu) << 4) | ((m >> 4) & 0x0fu); m = (oct & 4u) ? t : m;
+    return m;
+}
+LJ_HD Ray8 ray8_setup(const RayF &ray) {
+    Ray8 r;
+    r.ix = recip_fast(ray.dx); r.iy = recip_fast(ray.dy); r.iz = recip_fast(ray.dz);
+    r.oix = ray.ox * r.ix; r.oiy = ray.oy * r.iy; r.oiz = ray.oz * r.iz;
+    r.oct = (r.ix < 0.0f ? 1u : 0u) | (r.iy < 0.0f ? 2u : 0u) | (r.iz < 0.0f ? 4u : 0u);
+    return r;
+}
+LJ_HD int ctz32(uint32_t v) { return __builtin_ctz(v); }
+LJ_HD int popc32(uint32_t v) { return __builtin_popcount(v); }
+
+// Reference form of the BVH8 traversal (kernels.hip keeps a wave-synchronous version of the same steps).  A node group is
+// (child_base, remaining inner hits in octant order | imask << 8): one stack entry per visited node, however many of its children were hit.
+// Mem provides: const uint32_t *node8(int i); DPrim prim(int i); const DSphere& sphere(int slot);
+//               void push8(int sp, uint32_t base, uint32_t bits); void pop8(int sp, uint32_t &base, uint32_t &bits);
+template <bool ANY_HIT, class Mem>
+LJ_HD bool traverse8(Mem &mem, const RayF &ray, HitRec &best) {
+    best.t = ray.tfar; best.u = 0.0f; best.v = 0.0f; best.gprim = -1;
+    const Ray8 r8 = ray8_setup(ray);
+    uint32_t gbase = 0u, gbits = 1u;   // the root as a group of one: imask 0, so the child picked is node `gbase`
+    int sp = 0;
+    for (;;) {
+        if ((gbits & 0xffu) == 0u) {
+            if (sp == 0) break;
+            sp--; mem.pop8(sp, gbase, gbits);
+        }
+        const uint32_t k = (uint32_t)ctz32(gbits & 0xffu), s = k ^ r8.oct, imask = (gbits >> 8) & 0xffu;
+        gbits &= gbits - 1u;
+        const uint32_t node = gbase + (uint32_t)popc32(imask & ((1u << s) - 1u));
+        if (gbits & 0xffu) { mem.push8(sp, gbase, gbits); sp++; }
+        const uint32_t *w = mem.node8((int)node);
+        const uint32_t hits = node8_hits(w, r8, ray.tnear, best.t);
+        const uint32_t nmask = w[3] >> 24, inner = hits & nmask;
+        uint32_t leaf = hits & ~nmask;
+        while (leaf) {
+            const int slot = ctz32(leaf); leaf &= leaf - 1u;
+            const uint32_t m = (w[6 + (slot >> 2)] >> (8 * (slot & 3))) & 0xffu;
+            if (!(m & 0x80u)) continue;   // (an empty slot can pass the widened test of a degenerate node)
+            const int first = (int)(w[5] + (m & 31u)), count = (int)((m >> 5) & 3u) + 1;
+            for (int i = 0; i < count; i++)
+                if (leaf_prim_test<ANY_HIT>(mem, ray, mem.prim(first + i), best)) return true;
+        }
+        gbase = w[4]; gbits = inner ? (perm8(inner, r8.oct) | (nmask << 8)) : 0u;
+    }
+    return best.gprim >= 0;
+}
+
 } // namespace ljd
 
 #if defined(__clang__)

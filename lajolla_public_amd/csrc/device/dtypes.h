@@ -24,6 +24,29 @@ struct DNode4 {
 };
 static_assert(sizeof(DNode4) == 128, "DNode4 must be 128 bytes");
 
+// ---- BVH8 with quantised child boxes (80 bytes = five 16-byte quarters), for trees beyond the LDS image.  A traversal of such a
+// tree is bound by the bytes each step gathers through the texture-address path and by the number of dependent fetches per ray, not
+// by arithmetic: eight children per step make the chain ~0.6x as long as a BVH4's, 8-bit boxes on a per-node grid
+// (origin p, per-axis scale 2^(e-127): plane = p + q * 2^(e-127), lower planes rounded down, upper planes up — the quantised box always
+// contains the child's box) make a step 80 bytes instead of 112.  Children sit in octant-ordered slots: slot s holds the child that lies
+// towards corner s (bit k set: the high side of axis k) of the node, so that a ray whose direction signs are `oct` (bit k set: negative
+// along axis k) meets the slots roughly front to back in ascending (s ^ oct) — no distance sort (Ylitie, Karras, Laine: "Efficient
+// Incoherent Ray Traversal on GPUs Through Compressed Wide BVHs", HPG 2017, whose node this follows).
+// Inner children are consecutive nodes in slot order from child_base; the primitives of the leaf children are consecutive in slot order
+// from prim_base (at most 8 leaves x 4 primitives: a 5-bit offset).
+struct DNode8 {
+    float p[3];                 // quarter 0: grid origin = lower corner of the union of the children
+    uint8_t e[3];               //            biased exponents of the grid steps, one per axis
+    uint8_t imask;              //            slots that hold inner nodes
+    uint32_t child_base;        // quarter 1: node index of the first inner child
+    uint32_t prim_base;         //            leaf-ordered primitive index of the first leaf child's first primitive
+    uint8_t meta[8];            //            per slot: leaf = 0x80 | (count - 1) << 5 | offset from prim_base; inner or empty = 0
+    uint8_t qlo_x[8], qlo_y[8]; // quarter 2
+    uint8_t qlo_z[8], qhi_x[8]; // quarter 3
+    uint8_t qhi_y[8], qhi_z[8]; // quarter 4    (an empty slot has qlo = 255, qhi = 0 and is in neither imask nor meta)
+};
+static_assert(sizeof(DNode8) == 80, "DNode8 must be 80 bytes");
+
 // Leaf-ordered primitive for the intersection tests (48 bytes = three float4).
 // kind 0: triangle, float vertices exactly as the reference hands them to Embree (triangle_mesh.inl:11-14).
 // kind 1: sphere, `gprim` indexes DScene::prims and the sphere parameters are read from there (double maths).
@@ -116,6 +139,8 @@ struct DMedium {
 struct DScene {
     DCamera cam;
     const DNode4 *nodes; int32_t n_nodes;
+    const DNode8 *nodes8; int32_t n_nodes8;   // the same binary tree collapsed eight wide (same leaves, same leaf-ordered primitives)
+    int32_t node8_stride;                     // bytes between two nodes of nodes8 on the device (80, or 128: one node per cache line)
     const DPrim *leaf_prims; int32_t n_prims;
     const DPrimShade *prims;
     const DSphere *spheres;          // indexed by sphere_slot

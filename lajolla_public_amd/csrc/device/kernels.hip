@@ -22,6 +22,7 @@
 #include "dvol.h"
 #include "dtrace.h"
 #include "dconfig.h"
+#include "dpool.h"
 
 namespace ljd {
 
@@ -36,7 +37,6 @@ __device__ __forceinline__ void q_load_for_shade(const DQueue &q, uint32_t i, Pa
     ps.sample = f2u(rg.x); ps.rng = (uint64_t)f2u(rg.y) | ((uint64_t)f2u(rg.z) << 32); ps.p2 = rg.w;
     ps.sdir = mk3(0, 0, 0); ps.stfar = 0.0f;
 }
-__device__ __forceinline__ Rec4 mk4(float x, float y, float z, float w) { Rec4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
 __device__ __forceinline__ void q_store(const DQueue &q, uint32_t i, const PathState &ps) {
     q.ro[i] = mk4(ps.org.x, ps.org.y, ps.org.z, ps.stfar);
     q.rd[i] = mk4(ps.dir.x, ps.dir.y, ps.dir.z, u2f(ps.flags));
@@ -84,7 +84,6 @@ __device__ __forceinline__ TreeView stage_tree(const DScene &sc, int stack, int 
     return tv;
 }
 
-constexpr uint32_t kChunk = 256;   // queue slots a wave draws at a time (segments are multiples of it)
 constexpr int kDone = 0x7fffffff;  // "no more work for this ray" marker in `cur`
 
 struct LaneTrav {
@@ -260,28 +259,7 @@ __device__ __forceinline__ void trav_leaf_step(const TreeView &tv, LaneTrav &L, 
     L.cur = stop ? kDone : trav_pop<RESIDENT>(tv, L);
 }
 
-// ---- the leaf phase of k_extend, pooled.  In the while-while loop the lanes that sit on a leaf hold 1 ... 8 primitives each and the
-// others none: tested lane by lane, a primitive round runs at ~30 % lane occupancy (sponza 27 %, disney_bsdf 35 %).  Here the wave lists
-// its (ray, primitive) pairs in LDS and tests them 64 at a time on whichever lane is free; the ray of a pair comes from its owner's
-// registers (ds_bpermute), results are merged per owner by one 64-bit LDS minimum on (t, global primitive id) — the same order the
-// lane-by-lane test applies, so the hit record is the same, bit for bit — and the winner leaves its unnormalised barycentrics beside it.
-#ifndef LJ_EXT_POOL
-#define LJ_EXT_POOL 1
-#endif
-constexpr uint32_t kPoolCap = 256;                                      // pairs listed at a time (a wave holds at most 64 x 16: a held leaf and the one a lane sits on)
-constexpr uint32_t kWavePoolBytes = 64 * 8 + 64 * 16 + kPoolCap * 4;    // keys | winners (U, V, S, t) | items (owner lane | leaf-order primitive index << 6)
-struct LeafPool { LJ_LDS unsigned long long *keys; LJ_LDS v4f *win; LJ_LDS uint32_t *items; };
-
-__device__ __forceinline__ LeafPool leaf_pool_at(uint32_t at) {
-    LJ_LDS char *w = (LJ_LDS char *)lj_smem + at + (threadIdx.x >> 6) * kWavePoolBytes;
-    LeafPool lp;
-    lp.keys = (LJ_LDS unsigned long long *)w; lp.win = (LJ_LDS v4f *)(w + 64 * 8); lp.items = (LJ_LDS uint32_t *)(w + 64 * 8 + 64 * 16);
-    lp.keys[threadIdx.x & 63u] = ~0ull;
-    return lp;
-}
-__device__ __forceinline__ float lane_read(int src4, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src4, __float_as_int(v))); }
-
-// Called by the whole wave (the bpermutes need every owner lane active).  `at_leaf`: this lane's L.cur is a leaf.  Returns the number of
+// Called by the whole wave.  `at_leaf`: this lane's L.cur is a leaf.  Returns the number of
 // 64-pair rounds it ran (for the statistics); `n_pairs` the pairs.
 template <bool RESIDENT, bool SPHERES>
 __device__ __forceinline__ uint32_t trav_leaf_pool(const TreeView &tv, const LeafPool &lp, LaneTrav &L, const bool at_leaf, const bool any_hit, uint32_t &n_pairs) {
@@ -307,61 +285,12 @@ __device__ __forceinline__ uint32_t trav_leaf_pool(const TreeView &tv, const Lea
         n_pairs += n_items;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
         // ---- test them
-        for (uint32_t r = 0; r < n_items; r += 64u, rounds++) {
-            const bool act = r + lane < n_items;
-            const uint32_t it = act ? lp.items[r + lane] : lane;
-            const uint32_t src = it & 63u;
-            const int src4 = (int)(src << 2);
-            RayF ray;
-            ray.ox = lane_read(src4, L.ray.ox); ray.oy = lane_read(src4, L.ray.oy); ray.oz = lane_read(src4, L.ray.oz);
-            ray.dx = lane_read(src4, L.ray.dx); ray.dy = lane_read(src4, L.ray.dy); ray.dz = lane_read(src4, L.ray.dz);
-            ray.tnear = lane_read(src4, L.ray.tnear);
-            ray.tfar = SPHERES ? lane_read(src4, L.ray.tfar) : 0.0f;
-            const float tbest = lane_read(src4, L.best.t);
-            const int pi = (int)(it >> 6);
-            bool hit = false;
-            unsigned long long key = 0ull;
-            v4f w; w.x = 0.0f; w.y = 0.0f; w.z = 1.0f; w.w = 0.0f;
-            if (act) {
-                v4f p0, p1, p2;
-                if (RESIDENT || pi < tv.n_lprims) { const int S = tv.prim_stride; p0 = tv.lprims[pi]; p1 = tv.lprims[S + pi]; p2 = tv.lprims[2 * S + pi]; }
-                else { p0 = tv.gprims[3 * pi]; p1 = tv.gprims[3 * pi + 1]; p2 = tv.gprims[3 * pi + 2]; }
-                const int gprim = __float_as_int(p0.w);
-                if (!SPHERES || __float_as_int(p1.w) == 0) {
-                    const float v0[3] = {p0.x, p0.y, p0.z}, v1[3] = {p1.x, p1.y, p1.z}, v2[3] = {p2.x, p2.y, p2.z};
-                    float t = 0.0f, U = 0.0f, V = 0.0f, S = 1.0f;
-                    hit = tri_test_raw(ray, tbest, v0, v1, v2, t, U, V, S);   // t > tnear >= 0: its bits order like the value
-                    w.x = U; w.y = V; w.z = S; w.w = t;
-                    key = ((unsigned long long)f2u(t) << 32) | (unsigned long long)(uint32_t)gprim;
-                } else {
-                    double td = 0.0;
-                    hit = sphere_test(ray, tv.spheres[__float_as_int(p2.w)], td);
-                    const float t = (float)td;                                // t >= tnear >= 0; a zero of either sign orders as +0
-                    w.w = t;
-                    key = ((unsigned long long)(t == 0.0f ? 0u : f2u(t)) << 32) | (unsigned long long)(uint32_t)gprim;
-                }
-                if (hit) (void)__hip_atomic_fetch_min(&lp.keys[src], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            }
-            // (a wave's LDS operations complete in order: every pair's minimum has landed when the read below is issued)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-            if (hit && __hip_atomic_load(&lp.keys[src], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) == key) lp.win[src] = w;   // one winner per ray: a leaf holds a primitive once
-        }
+        pool_test_items<RESIDENT, SPHERES>(tv, lp, L, n_items, rounds);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
     }
-    // ---- every owner picks up its result: the rule of trav_leaf_step on (t, gprim)
+    // ---- every owner picks up its result
     if (at_leaf) {
-        bool stop = false;
-        const unsigned long long key = lp.keys[lane];
-        if (key != ~0ull) {
-            lp.keys[lane] = ~0ull;
-            const int gprim = (int)(uint32_t)key;
-            const v4f w = lp.win[lane];
-            // (selects, as in trav_leaf_step: an any-hit ray only needs `gprim`)
-            const bool take = any_hit | (w.w < L.best.t) | ((w.w == L.best.t) & ((L.best.gprim < 0) | (gprim < L.best.gprim)));
-            L.best.t = take ? w.w : L.best.t; L.best.u = take ? w.x : L.best.u; L.best.v = take ? w.y : L.best.v;
-            L.best_S = take ? w.z : L.best_S; L.best.gprim = take ? gprim : L.best.gprim;
-            stop = any_hit;
-        }
+        const bool stop = pool_collect(lp, L, any_hit);
         const bool on_leaf = L.cur < 0;
         L.held = 0;
         if (stop) L.cur = kDone;
@@ -684,8 +613,6 @@ __global__ void __launch_bounds__(kBlock) k_resolve(DPass pass, uint32_t n_pixel
 }
 
 // ---------------------------------------------------------------- batched ray queries for the parity tests
-struct RayIO { float org[3]; float tnear; float dir[3]; float tfar; };
-struct HitIO { float t, u, v; int32_t shape_id, prim_id; };
 
 // (wave-complete iterations over the rays and the same two phases as k_extend — inner nodes lane by lane, leaves pooled — so that the
 // parity tests of intersect() / occluded() hold the pooled leaf phase to the oracle, bit for bit)
@@ -814,8 +741,8 @@ __global__ void __launch_bounds__(kBlock, 3) k_volpath3(DScene sc, DPass pass, u
 // LDS per 256-thread workgroup = stack * 1 KiB + staged nodes * 112 B + staged prims * 48 B; four workgroups share a
 // CU's 160 KiB, so the budget per workgroup is 40 KiB.
 
-ExtendConfig extend_config(int n_nodes, int n_prims, int bvh_depth, int n_spheres) {
-    ExtendConfig c;
+ExtendConfig extend_config(int n_nodes, int n_prims, int bvh_depth, int n_spheres, int n_nodes8, int bvh8_depth) {
+    ExtendConfig c{};
     c.spheres = n_spheres > 0 ? 1 : 0;
     const int need = 3 * (bvh_depth < 1 ? 1 : bvh_depth);
     // LDS image: small scenes (which may become fully resident) get 16 stack levels and up to 40 KiB; for the others 12
@@ -843,6 +770,29 @@ ExtendConfig extend_config(int n_nodes, int n_prims, int bvh_depth, int n_sphere
     // (sponza / disney_bsdf at 64 spp: 16: 65.2 / 30.6 ms, 24: 64.2 / 30.0, 32: 63.2 / 29.7, 40: 63.3 / 30.3, 48: 67.8 / 31.9; with held
     // leaves — a lane that reaches a leaf keeps descending until its second one — 24: 62.6 / 27.8, 32: 61.7 / 27.5, 40: 60.9 / 27.4)
     c.refill_min = 8; c.min_descending = (n_nodes <= c.lds_nodes) ? 1 : (LJ_EXT_POOL ? (LJ_EXT_HOLD ? 40 : 32) : 24);
+    // A tree beyond the LDS image can be traversed as a BVH8 instead (k_extend8, extend8.hip): 8-byte group entries, at most one push per
+    // step, 80-byte nodes.  Measured on MI355X (tools/bvh8_ab.sh, tools/ab1024.sh, profiles/r03_bvh8_ab.txt): 26 % fewer node steps per ray
+    // and a third fewer vector-memory instructions, but 26 % more VALU instructions (eight quantised children cost ~200 per step), and with
+    // five waves per SIMD the extend kernel is bound by instruction issue, not by the gather path — sponza 1024 spp 815 ms against 784 with
+    // the BVH4 kernel, disney_bsdf 256 spp 88.5 against 90.6.  So the BVH4 kernel stays the default and LJ_TUNE_BVH8=1 selects this one.
+    // A ray's stack is rarely more than four groups deep (sponza: 1 push in 600 lands on level 4, 1 in 10^5 on level 6), so six levels
+    // live in LDS and the rest of the tree's depth goes to the global overflow buffer; with the first 96 nodes (three full levels and part
+    // of the fourth) and the pools a workgroup takes 29.5 KiB: five per CU.  `spill_levels` counts 4-byte units per lane (ensure_spill):
+    // two per group level.
+    c.wide = 0;
+    if (const char *e = getenv("LJ_TUNE_BVH8")) c.wide = (atoi(e) != 0 && !c.resident && n_nodes > c.lds_nodes && n_nodes8 > 0) ? 1 : 0;
+    if (c.wide) {
+        int cap8 = 6, nodes8 = 96;
+        if (const char *e = getenv("LJ_TUNE_EXT8_STACK")) cap8 = atoi(e);
+        if (const char *e = getenv("LJ_TUNE_EXT8_NODES")) nodes8 = atoi(e);
+        const int need8 = bvh8_depth < 1 ? 1 : bvh8_depth;
+        c.stack8 = need8 < cap8 ? need8 : cap8;
+        if (c.stack8 < 1) c.stack8 = 1;
+        c.lds_nodes8 = n_nodes8 < nodes8 ? n_nodes8 : nodes8;
+        c.smem8 = (size_t)c.stack8 * kBlock * 8 + (size_t)c.lds_nodes8 * 80;
+        const int spill8 = 2 * (need8 - c.stack8 > 0 ? need8 - c.stack8 : 0);
+        if (spill8 > c.spill_levels) c.spill_levels = spill8;   // (k_aux / k_volpath still walk the BVH4 with the 4-byte levels)
+    }
     return c;
 }
 int max_stack_depth() { return 40; }  // inner levels; the builder's own cap is 38
@@ -868,6 +818,7 @@ ShadeConfig shade_config(size_t n_prims, size_t n_materials, size_t n_lights, si
 // LDS of an extend launch: the traversal image, then the leaf pools of its four waves
 size_t extend_smem(const ExtendConfig &cfg) { return ((cfg.smem + 15) & ~(size_t)15) + (LJ_EXT_POOL ? (kBlock / 64) * kWavePoolBytes : 0); }
 void launch_extend(const DScene &sc, const DQueue &q, const DBlockState *blocks, uint32_t grid, uint32_t seg, uint32_t *work, const uint32_t *chunk_list, uint32_t parity, const ExtendConfig &cfg, int *spill, unsigned long long *stats, hipStream_t s) {
+    if (cfg.wide) { launch_extend8(sc, q, blocks, grid, seg, work, chunk_list, parity, cfg, spill, stats, s); return; }
     auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), extend_smem(cfg), s, sc, q, blocks, seg, work, chunk_list, parity, cfg.stack, cfg.lds_nodes, cfg.lds_prims, spill, cfg.refill_min, cfg.min_descending, stats,
                            (uint32_t)((cfg.smem + 15) & ~(size_t)15));
@@ -934,6 +885,7 @@ void launch_volpath(const DScene &sc, const DPass &pass, uint32_t n_samples, uns
     else hipLaunchKernelGGL(k_volpath3, dim3(grid), dim3(kBlock), cfg.smem, s, sc, pass, n_samples, bounce_counter, cfg.stack, cfg.lds_nodes, cfg.lds_prims, spill);
 }
 void launch_trace_rays(const DScene &sc, const void *rays, long long n, void *hits, unsigned char *occ, const ExtendConfig &cfg, int *spill, int grid, hipStream_t s) {
+    if (cfg.wide) { launch_trace_rays8(sc, rays, n, hits, occ, cfg, spill, grid, s); return; }
     hipLaunchKernelGGL(k_trace_rays, dim3(grid), dim3(kBlock), extend_smem(cfg), s, sc, (const RayIO *)rays, n, (HitIO *)hits, occ, cfg.stack, cfg.lds_nodes, cfg.lds_prims, spill, (uint32_t)((cfg.smem + 15) & ~(size_t)15));
 }
 

@@ -205,9 +205,23 @@ struct Builder {
 
 } // namespace
 
+// ---- the binary tree collapsed eight wide, children quantised on a per-node grid (device/dtypes.h DNode8)
+namespace {
+
+// grid step exponent for one axis: the smallest e with 255 * 2^e >= extent (so every plane of the node fits 8 bits)
+int grid_exponent(double extent) {
+    int e = -126;
+    if (extent > 0) { e = (int)std::ceil(std::log2(extent / 255.0)); if (e < -126) e = -126; }
+    while (std::ldexp(255.0, e) < extent) e++;
+    if (e > 127) throw LjError(LJ_ERR_UNSUPPORTED, "scene extent beyond the float range of the BVH grid");
+    return e;
+}
+
+} // namespace
+
 void build_bvh(const std::vector<BuildPrim> &prims, int max_leaf, int max_depth,
-               std::vector<ljd::DNode4> &nodes, std::vector<int> &leaf_order, int &depth_out) {
-    nodes.clear(); leaf_order.clear(); depth_out = 0;
+               std::vector<ljd::DNode4> &nodes, std::vector<ljd::DNode8> &nodes8, std::vector<int> &leaf_order, int &depth_out, int &depth8_out) {
+    nodes.clear(); nodes8.clear(); leaf_order.clear(); depth_out = 0; depth8_out = 0;
     const int n = (int)prims.size();
     const float inf = std::numeric_limits<float>::infinity();
     auto empty_node = [&]() {
@@ -215,13 +229,20 @@ void build_bvh(const std::vector<BuildPrim> &prims, int max_leaf, int max_depth,
         for (int k = 0; k < 4; k++) { nd.lox[k] = nd.loy[k] = nd.loz[k] = inf; nd.hix[k] = nd.hiy[k] = nd.hiz[k] = -inf; nd.child[k] = 0; }
         return nd;
     };
-    if (n == 0) { nodes.push_back(empty_node()); depth_out = 1; return; }
+    auto empty_node8 = [&]() {
+        ljd::DNode8 nd{};
+        for (int k = 0; k < 3; k++) nd.e[k] = 1;
+        for (int k = 0; k < 8; k++) { nd.qlo_x[k] = nd.qlo_y[k] = nd.qlo_z[k] = 255; nd.qhi_x[k] = nd.qhi_y[k] = nd.qhi_z[k] = 0; }
+        return nd;
+    };
+    if (n == 0) { nodes.push_back(empty_node()); nodes8.push_back(empty_node8()); depth_out = 1; depth8_out = 1; return; }
     // Spatial splits for scenes beyond the tiny ones (those run the flat leaf scan of mega.hip, which indexes primitives with 16 bits
     // and wants no duplicates); at most twice as many references as primitives (sponza ends at 1.36x: -16 % node steps and -30 %
     // primitive tests per extension ray against the object-split tree).  LJ_TUNE_SBVH=0 turns them off.
     const bool spatial = n > 256 && !(getenv("LJ_TUNE_SBVH") && atoi(getenv("LJ_TUNE_SBVH")) == 0);
     double budget = 1.0;
     if (const char *e = getenv("LJ_TUNE_SBVH_BUDGET")) budget = atof(e);
+    if (max_leaf > 4) max_leaf = 4;   // (a DNode8 addresses the primitives of its leaf children with 5-bit offsets: 8 leaves x 4)
     Builder b{prims, {}, {}, max_leaf, max_depth, spatial, (size_t)n + (size_t)(budget * n), (size_t)n, 0.0f};
     std::vector<Ref> refs((size_t)n);
     Box rootb;
@@ -233,18 +254,105 @@ void build_bvh(const std::vector<BuildPrim> &prims, int max_leaf, int max_depth,
     b.order.reserve((size_t)n + n / 3);
     b.tmp.reserve(2 * (size_t)n);
     const int root = b.build(refs, 0);
-    // Leaves hold at most 8 primitives (3-bit count in the child code); beyond the depth cap the builder keeps
-    // splitting until that holds, and the caller checks the resulting depth against its traversal stack.
     if ((long long)n * 8 >= (1ll << 30)) throw LjError(LJ_ERR_UNSUPPORTED, "too many primitives for the 30-bit leaf code");
-    leaf_order = b.order;
+    // Beyond the depth cap the builder stops at leaves of up to 8 primitives (coincident primitives cannot be separated); the wide
+    // nodes want at most 4 per leaf, so such a leaf becomes an inner node over two leaves with its own box.
+    for (size_t id = 0; id < b.tmp.size(); id++) {
+        if (b.tmp[id].left >= 0 || b.tmp[id].count <= 4) continue;
+        TmpNode l = b.tmp[id], r = b.tmp[id];
+        l.count = 4; r.first = l.first + 4; r.count = b.tmp[id].count - 4; l.depth = r.depth = b.tmp[id].depth + 1;
+        b.tmp[id].left = (int)b.tmp.size(); b.tmp.push_back(l);
+        b.tmp[id].right = (int)b.tmp.size(); b.tmp.push_back(r);
+    }
     auto is_leaf = [&](int id) { return b.tmp[id].left < 0; };
+
+    // ---- BVH8 first: it fixes the leaf order (the primitives of a wide node's leaf children are consecutive, in slot order)
+    std::vector<int> new_first(b.tmp.size(), -1);   // binary leaf id -> position of its first primitive in leaf_order
+    {
+        struct Wide8 { int kids[8]; int n; int depth; };
+        std::vector<int> queue{root}, qdepth{1};
+        const bool root_leaf = is_leaf(root);
+        for (size_t h = 0; h < queue.size(); h++) {
+            Wide8 w; w.depth = qdepth[h];
+            if (root_leaf) { w.kids[0] = root; w.n = 1; }
+            else {
+                const TmpNode &t = b.tmp[queue[h]];
+                w.kids[0] = t.left; w.kids[1] = t.right; w.n = 2;
+                while (w.n < 8) {   // open the inner child with the largest surface area
+                    int pick = -1; float area = -1.0f;
+                    for (int k = 0; k < w.n; k++) if (!is_leaf(w.kids[k])) { const float a = b.tmp[w.kids[k]].box.half_area(); if (a > area) { area = a; pick = k; } }
+                    if (pick < 0) break;
+                    const TmpNode &c = b.tmp[w.kids[pick]];
+                    w.kids[pick] = c.left; w.kids[w.n++] = c.right;
+                }
+            }
+            depth8_out = std::max(depth8_out, w.depth);
+            // grid: origin = lower corner of the union, one power-of-two step per axis
+            Box u; for (int k = 0; k < w.n; k++) u.grow(b.tmp[w.kids[k]].box);
+            ljd::DNode8 nd = empty_node8();
+            double step[3];
+            for (int a = 0; a < 3; a++) {
+                nd.p[a] = u.lo[a];
+                const int e = grid_exponent((double)u.hi[a] - (double)u.lo[a]);
+                nd.e[a] = (uint8_t)(e + 127); step[a] = std::ldexp(1.0, e);
+            }
+            // octant-ordered slots: child c goes to the free slot s that maximises (centre_c - centre_node) . corner_s, best pairs first
+            int slot_of[8]; bool slot_used[8] = {false}, kid_done[8] = {false};
+            double ctr[3]; for (int a = 0; a < 3; a++) ctr[a] = 0.5 * ((double)u.lo[a] + (double)u.hi[a]);
+            for (int round = 0; round < w.n; round++) {
+                double best = -std::numeric_limits<double>::infinity(); int bc = -1, bs = -1;
+                for (int c = 0; c < w.n; c++) if (!kid_done[c]) {
+                    const Box &cb = b.tmp[w.kids[c]].box;
+                    for (int s = 0; s < 8; s++) if (!slot_used[s]) {
+                        double v = 0;
+                        for (int a = 0; a < 3; a++) v += (0.5 * ((double)cb.lo[a] + (double)cb.hi[a]) - ctr[a]) * ((s >> a) & 1 ? 1.0 : -1.0);
+                        if (v > best) { best = v; bc = c; bs = s; }
+                    }
+                }
+                slot_of[bc] = bs; slot_used[bs] = true; kid_done[bc] = true;
+            }
+            int kid_at[8]; for (int s = 0; s < 8; s++) kid_at[s] = -1;
+            for (int c = 0; c < w.n; c++) kid_at[slot_of[c]] = w.kids[c];
+            nd.child_base = (uint32_t)queue.size(); nd.prim_base = (uint32_t)leaf_order.size();
+            for (int s = 0; s < 8; s++) {
+                const int id = kid_at[s];
+                if (id < 0) continue;
+                const Box &cb = b.tmp[id].box;
+                uint8_t *qlo[3] = {nd.qlo_x, nd.qlo_y, nd.qlo_z}, *qhi[3] = {nd.qhi_x, nd.qhi_y, nd.qhi_z};
+                for (int a = 0; a < 3; a++) {   // lower planes down, upper planes up, checked in exact arithmetic (q * step is exact in double)
+                    const double p = nd.p[a];
+                    long lo = (long)std::floor(((double)cb.lo[a] - p) / step[a]), hi = (long)std::ceil(((double)cb.hi[a] - p) / step[a]);
+                    lo = std::min(255l, std::max(0l, lo)); hi = std::min(255l, std::max(0l, hi));
+                    while (lo > 0 && p + lo * step[a] > (double)cb.lo[a]) lo--;
+                    while (hi < 255 && p + hi * step[a] < (double)cb.hi[a]) hi++;
+                    if (p + lo * step[a] > (double)cb.lo[a] || p + hi * step[a] < (double)cb.hi[a]) throw LjError(LJ_ERR_INTERNAL, "BVH8 grid does not contain a child box");
+                    qlo[a][s] = (uint8_t)lo; qhi[a][s] = (uint8_t)hi;
+                }
+                if (is_leaf(id)) {
+                    const TmpNode &t = b.tmp[id];
+                    const uint32_t off = (uint32_t)leaf_order.size() - nd.prim_base;
+                    nd.meta[s] = (uint8_t)(0x80u | ((uint32_t)(t.count - 1) << 5) | off);
+                    new_first[id] = (int)leaf_order.size();
+                    for (int i = 0; i < t.count; i++) leaf_order.push_back(b.order[t.first + i]);
+                } else {
+                    nd.imask |= (uint8_t)(1u << s);
+                    queue.push_back(id); qdepth.push_back(w.depth + 1);
+                }
+            }
+            nodes8.push_back(nd);
+            if (root_leaf) break;
+        }
+        if (nodes8.size() >= (1u << 24)) throw LjError(LJ_ERR_UNSUPPORTED, "too many BVH8 nodes for the 24-bit node index");
+    }
+
+    // ---- BVH4 over the same leaves
     auto set_child = [&](ljd::DNode4 &nd, int k, int id, int code) {
         const Box &bx = b.tmp[id].box;
         nd.lox[k] = bx.lo[0]; nd.loy[k] = bx.lo[1]; nd.loz[k] = bx.lo[2];
         nd.hix[k] = bx.hi[0]; nd.hiy[k] = bx.hi[1]; nd.hiz[k] = bx.hi[2];
         nd.child[k] = code;
     };
-    auto leaf_code = [&](int id) { return ~(b.tmp[id].first * 8 + b.tmp[id].count - 1); };
+    auto leaf_code = [&](int id) { return ~(new_first[id] * 8 + b.tmp[id].count - 1); };
     if (is_leaf(root)) {
         ljd::DNode4 nd = empty_node();
         set_child(nd, 0, root, leaf_code(root));

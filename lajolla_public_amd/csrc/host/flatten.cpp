@@ -73,6 +73,7 @@ ljd::DScene FlatScene::host_view() const {
     ljd::DScene s{};
     s.cam = cam;
     s.nodes = nodes.data(); s.n_nodes = (int)nodes.size();
+    s.nodes8 = nodes8.data(); s.n_nodes8 = (int)nodes8.size(); s.node8_stride = (int32_t)sizeof(ljd::DNode8);
     s.leaf_prims = leaf_prims.data(); s.n_prims = (int)leaf_prims.size();
     s.prims = prims.data(); s.spheres = spheres.data();
     s.materials = materials.data(); s.n_materials = (int)materials.size();
@@ -267,8 +268,8 @@ FlatScene flatten_scene(const LjSceneDesc &d) {
     // ---- BVH (replaces rtcCommitScene)
     std::vector<int> order;
     int max_leaf = 4;
-    if (const char *e = getenv("LJ_TUNE_MAX_LEAF")) max_leaf = std::min(8, std::max(1, atoi(e)));
-    build_bvh(bprims, max_leaf, 38, F.nodes, order, F.bvh_depth);
+    if (const char *e = getenv("LJ_TUNE_MAX_LEAF")) max_leaf = std::min(4, std::max(1, atoi(e)));
+    build_bvh(bprims, max_leaf, 38, F.nodes, F.nodes8, order, F.bvh_depth, F.bvh8_depth);
     F.leaf_prims.resize(order.size());   // (>= gprims.size(): a primitive cut by a spatial split sits in a leaf on either side)
     for (size_t i = 0; i < order.size(); i++) F.leaf_prims[i] = gprims[order[i]];
     // ---- flat leaf table of a tiny scene (device/dscan.h): the leaves of the tree with their (padded) boxes, one 32-byte

@@ -12,6 +12,7 @@ namespace lj {
 struct FlatScene {
     ljd::DCamera cam{};
     std::vector<ljd::DNode4> nodes;
+    std::vector<ljd::DNode8> nodes8;   // the same tree eight wide with quantised boxes (trees beyond the extend kernel's LDS image)
     std::vector<ljd::DPrim> leaf_prims;
     std::vector<ljd::DPrimShade> prims;
     std::vector<ljd::DSphere> spheres;
@@ -29,7 +30,7 @@ struct FlatScene {
     std::vector<ljd::DScanLeaf> scan_leaves;   // tiny scenes only (else empty): the flat leaf table of device/dscan.h
     int cam_medium = -1, max_null_collisions = 1000, vol_path_version = 0;
     int envmap_light_id = -1, max_depth = -1, rr_depth = 5, spp = 4, integrator = LJ_INTEGRATOR_PATH;
-    int bvh_depth = 0;
+    int bvh_depth = 0, bvh8_depth = 0;
     int64_t n_triangles = 0, n_spheres = 0;
     double bounds_radius = 0, bounds_center[3] = {0, 0, 0}, shadow_epsilon = 0;
     // double-precision tables kept for inspection by tests (scene.cpp:47-52)
@@ -48,7 +49,8 @@ FlatScene flatten_scene(const LjSceneDesc &d);
 // only its box is known (spheres).  leaf_order lists the primitives of the leaves one leaf after the other; with spatial
 // splits a primitive that straddles a split plane is referenced by a leaf on either side, so the list may be longer than `prims`.
 struct BuildPrim { float lo[3], hi[3]; float v[3][3]; int tri; };
+// nodes8 / depth8_out: the same binary tree collapsed eight wide (DNode8); a traversal of it holds at most depth8_out node groups.
 void build_bvh(const std::vector<BuildPrim> &prims, int max_leaf, int max_depth,
-               std::vector<ljd::DNode4> &nodes, std::vector<int> &leaf_order, int &depth_out);
+               std::vector<ljd::DNode4> &nodes, std::vector<ljd::DNode8> &nodes8, std::vector<int> &leaf_order, int &depth_out, int &depth8_out);
 
 } // namespace lj

@@ -227,6 +227,28 @@ class Twin:
         self.lib.twin_intersect(self.h, C.c_int64(rays.shape[0]), rays.ctypes.data_as(C.c_void_p), hits.ctypes.data_as(C.c_void_p))
         return hits
 
+    def intersect8(self, rays, work=None):
+        """The same query over the scene's BVH8 (DNode8); work: uint64[2] accumulating node steps and primitive tests."""
+        hits = np.zeros(rays.shape[0], lj.HIT_DTYPE)
+        self.lib.twin_intersect8(self.h, C.c_int64(rays.shape[0]), rays.ctypes.data_as(C.c_void_p), hits.ctypes.data_as(C.c_void_p),
+                                 work.ctypes.data_as(C.c_void_p) if work is not None else None)
+        return hits
+
+    def occluded8(self, rays):
+        occ = np.zeros(rays.shape[0], np.uint8)
+        self.lib.twin_occluded8(self.h, C.c_int64(rays.shape[0]), rays.ctypes.data_as(C.c_void_p), occ.ctypes.data_as(C.c_void_p))
+        return occ.astype(bool)
+
+    def intersect_work(self, rays):
+        work = np.zeros(2, np.uint64)
+        self.lib.twin_intersect_work(self.h, C.c_int64(rays.shape[0]), rays.ctypes.data_as(C.c_void_p), work.ctypes.data_as(C.c_void_p))
+        return work
+
+    def bvh8_info(self):
+        out = np.zeros(4, np.int64)
+        self.lib.twin_bvh8_info(self.h, out.ctypes.data_as(C.c_void_p))
+        return dict(nodes=int(out[0]), depth=int(out[1]), filled_slots=int(out[2]), leaf_slots=int(out[3]))
+
     def occluded(self, rays):
         occ = np.zeros(rays.shape[0], np.uint8)
         self.lib.twin_occluded(self.h, C.c_int64(rays.shape[0]), rays.ctypes.data_as(C.c_void_p), occ.ctypes.data_as(C.c_void_p))

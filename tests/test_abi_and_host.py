@@ -91,6 +91,13 @@ def test_bvh_traversal_equals_brute_force(name):
     rays2["tnear"] = 1e-3
     rays2["tfar"] = np.random.default_rng(3).random(len(rays)).astype(np.float32) * o.tables()["bounds_radius"]
     assert np.array_equal(o.occluded(rays2), tw.occluded(rays2))
+    # the same tree collapsed eight wide with quantised child boxes (DNode8, what k_extend8 walks for trees beyond its LDS image)
+    h8 = tw.intersect8(rays)
+    for f in ("t", "u", "v", "shape_id", "prim_id"):
+        assert np.array_equal(ho[f].view(np.uint32), h8[f].view(np.uint32)), "bvh8 " + f
+    assert np.array_equal(o.occluded(rays2), tw.occluded8(rays2))
+    info = tw.bvh8_info()
+    assert info["nodes"] >= 1 and info["filled_slots"] >= info["leaf_slots"] >= 1 and info["depth"] <= 40
     # and the oracle's own median-split BVH agrees with its brute force
     o.use_bvh(True)
     hb = o.intersect(rays)

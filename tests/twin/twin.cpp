@@ -28,6 +28,11 @@ struct HostMem {
     const DSphere &sphere(int s) const { return sc.spheres[s]; }
     void push(int sp, int v) { stack[sp] = v; }
     int pop(int sp) const { return stack[sp]; }
+    // the BVH8 twin of the same tree (dtrace.h traverse8)
+    uint32_t stack8[2 * 64];
+    const uint32_t *node8(int i) const { n_nodes++; return reinterpret_cast<const uint32_t *>(&sc.nodes8[i]); }
+    void push8(int sp, uint32_t base, uint32_t bits) { stack8[2 * sp] = base; stack8[2 * sp + 1] = bits; }
+    void pop8(int sp, uint32_t &base, uint32_t &bits) const { base = stack8[2 * sp]; bits = stack8[2 * sp + 1]; }
 };
 
 // traversal work counters (debugging aid): [shadow rays, shadow nodes, shadow prims, ext rays, ext nodes, ext prims]
@@ -51,7 +56,8 @@ void extend_one(const DScene &sc, PathState &ps) {
     if (ps.stfar > 0.0f) {
         ray.dx = ps.sdir.x; ray.dy = ps.sdir.y; ray.dz = ps.sdir.z; ray.tnear = sc.eps; ray.tfar = ps.stfar;
         HitRec h;
-        if (!traverse<true>(mem, ray, h)) code |= HIT_VIS_BIT;
+        static const bool wide = getenv("LJ_TWIN_BVH8") != nullptr;   // developer aid: the same rays over the BVH8 (work counters below)
+        if (!(wide ? traverse8<true>(mem, ray, h) : traverse<true>(mem, ray, h))) code |= HIT_VIS_BIT;
         if (getenv("LJ_TWIN_TRAV")) g_trav[6] += count_leaf_boxes(sc, ray);
         g_trav[0]++; g_trav[1] += mem.n_nodes; g_trav[2] += mem.n_prims; mem.n_nodes = mem.n_prims = 0;
     }
@@ -60,7 +66,8 @@ void extend_one(const DScene &sc, PathState &ps) {
         ray.dx = ps.dir.x; ray.dy = ps.dir.y; ray.dz = ps.dir.z;
         ray.tnear = ((ps.flags & 0xffffu) == 2u) ? 0.0f : sc.eps; ray.tfar = INFINITY;
         HitRec h;
-        if (traverse<false>(mem, ray, h)) { code |= (h.gprim + 1); t = h.t; u = h.u; v = h.v; }
+        static const bool wide = getenv("LJ_TWIN_BVH8") != nullptr;
+        if (wide ? traverse8<false>(mem, ray, h) : traverse<false>(mem, ray, h)) { code |= (h.gprim + 1); t = h.t; u = h.u; v = h.v; }
         if (getenv("LJ_TWIN_TRAV")) g_trav[7] += count_leaf_boxes(sc, ray);
         g_trav[3]++; g_trav[4] += mem.n_nodes; g_trav[5] += mem.n_prims;
     }
@@ -318,6 +325,47 @@ void twin_intersect(void *tv, int64_t n, const LjRay *rays, LjHit *hits) {
         HitRec h; LjHit o{0, 0, 0, -1, -1};
         if (traverse<false>(mem, r, h)) { const DPrimShade &ps = sc.prims[h.gprim]; o = LjHit{h.t, h.u, h.v, ps.shape_id, ps.prim_id}; }
         hits[i] = o;
+    }
+}
+// the same queries over the BVH8 (DNode8) of the scene; work[0..1] += node steps, primitive tests
+void twin_intersect8(void *tv, int64_t n, const LjRay *rays, LjHit *hits, unsigned long long *work) {
+    Twin *t = (Twin *)tv;
+    const DScene &sc = t->view;
+    HostMem mem(sc);
+    for (int64_t i = 0; i < n; i++) {
+        RayF r; r.ox = rays[i].org[0]; r.oy = rays[i].org[1]; r.oz = rays[i].org[2]; r.dx = rays[i].dir[0]; r.dy = rays[i].dir[1]; r.dz = rays[i].dir[2];
+        r.tnear = rays[i].tnear; r.tfar = rays[i].tfar;
+        HitRec h; LjHit o{0, 0, 0, -1, -1};
+        if (traverse8<false>(mem, r, h)) { const DPrimShade &ps = sc.prims[h.gprim]; o = LjHit{h.t, h.u, h.v, ps.shape_id, ps.prim_id}; }
+        hits[i] = o;
+    }
+    if (work) { work[0] += mem.n_nodes; work[1] += mem.n_prims; }
+}
+void twin_occluded8(void *tv, int64_t n, const LjRay *rays, uint8_t *occ) {
+    Twin *t = (Twin *)tv;
+    HostMem mem(t->view);
+    for (int64_t i = 0; i < n; i++) {
+        RayF r; r.ox = rays[i].org[0]; r.oy = rays[i].org[1]; r.oz = rays[i].org[2]; r.dx = rays[i].dir[0]; r.dy = rays[i].dir[1]; r.dz = rays[i].dir[2];
+        r.tnear = rays[i].tnear; r.tfar = rays[i].tfar;
+        HitRec h; occ[i] = traverse8<true>(mem, r, h) ? 1 : 0;
+    }
+}
+void twin_intersect_work(void *tv, int64_t n, const LjRay *rays, unsigned long long *work) {   // BVH4 node steps / primitive tests of the same rays
+    Twin *t = (Twin *)tv;
+    HostMem mem(t->view);
+    for (int64_t i = 0; i < n; i++) {
+        RayF r; r.ox = rays[i].org[0]; r.oy = rays[i].org[1]; r.oz = rays[i].org[2]; r.dx = rays[i].dir[0]; r.dy = rays[i].dir[1]; r.dz = rays[i].dir[2];
+        r.tnear = rays[i].tnear; r.tfar = rays[i].tfar;
+        HitRec h; traverse<false>(mem, r, h);
+    }
+    work[0] += mem.n_nodes; work[1] += mem.n_prims;
+}
+void twin_bvh8_info(void *tv, long long *out) {   // nodes, depth, filled slots, leaf slots
+    Twin *t = (Twin *)tv;
+    out[0] = (long long)t->flat.nodes8.size(); out[1] = t->flat.bvh8_depth; out[2] = out[3] = 0;
+    for (const auto &nd : t->flat.nodes8) for (int s = 0; s < 8; s++) {
+        if (nd.imask & (1u << s)) out[2]++;
+        else if (nd.meta[s] & 0x80u) { out[2]++; out[3]++; }
     }
 }
 void twin_occluded(void *tv, int64_t n, const LjRay *rays, uint8_t *occ) {
