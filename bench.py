@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_HBM_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 COPY_HBM_GBS = 6290.0      # what a float4 copy kernel achieves on it (same guide): the practical ceiling
-ROUND = "r02"              # profiles/<ROUND>_* hold this round's rocprofv3 evidence
+ROUND = "r03"              # profiles/<ROUND>_* hold this round's rocprofv3 evidence
 
 
 def host_cores():
@@ -53,25 +53,46 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
-def profiled_counters(kernel):
-    """Hardware counters of `kernel` from this round's committed rocprofv3 PMC passes of the same workload
-    (profiles/<ROUND>_counters.json, written by tools/evidence_r02.sh: FETCH_SIZE, WRITE_SIZE and two SQ sets in separate
-    runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16 B/lane streams; totals over one render's launches).
+_COUNTERS = None
+
+
+def _load_counters():
+    global _COUNTERS
+    if _COUNTERS is None:
+        path = os.path.join(ROOT, "profiles", f"{ROUND}_counters.json")
+        try:
+            t = json.load(open(path))
+        except (OSError, ValueError):
+            _COUNTERS = (None, f"no profiles/{ROUND}_counters.json")
+            return _COUNTERS
+        if t.get("kernel_source_sha") != kernel_source_sha():
+            _COUNTERS = (None, f"profiles/{ROUND}_counters.json was measured on other kernel sources (stale)")
+        else:
+            _COUNTERS = (t, None)
+    return _COUNTERS
+
+
+def profiled_counters(workload):
+    """Hardware counters per kernel of `workload` ("cbox.xml@256", "sponza.xml@1024" ...) from this round's committed rocprofv3 PMC passes
+    (profiles/<ROUND>_counters.json, written by tools/evidence_r03.sh: SQ sets for every bench workload, FETCH_SIZE / WRITE_SIZE in
+    separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16 B/lane streams; totals over one render's launches).
     Returns (None, reason) when the file is missing or was measured on other kernel sources: a stale profile is never quoted."""
-    path = os.path.join(ROOT, "profiles", f"{ROUND}_counters.json")
-    try:
-        t = json.load(open(path))
-    except (OSError, ValueError):
-        return None, f"no profiles/{ROUND}_counters.json"
-    if t.get("kernel_source_sha") != kernel_source_sha():
-        return None, f"profiles/{ROUND}_counters.json was measured on other kernel sources (stale)"
-    k = t.get("kernels", {}).get(kernel)
-    if not k or "fetch_bytes" not in k or "write_bytes" not in k:
-        return None, f"{kernel} not in profiles/{ROUND}_counters.json"
-    out = dict(k)
-    out["traffic"] = int((k["fetch_bytes"] + k["write_bytes"]) / max(k["launches"], 1))
-    out["source"] = t.get("source")
+    t, why = _load_counters()
+    if t is None:
+        return None, why
+    k = t.get("workloads", {}).get(workload)
+    if not k:
+        return None, f"{workload} not in profiles/{ROUND}_counters.json"
+    # the extend kernels (k_extend, k_extend8) report under one name, as the library's per-kernel timers do
+    out = {}
+    for name, e in k.items():
+        out["k_extend" if name.startswith("k_extend") else name] = e
     return out, None
+
+
+def profiled_counters_source():
+    t, _ = _load_counters()
+    return t.get("source") if t else None
 
 
 def cpu_baseline(scene_xml, seconds_budget=12.0):
@@ -158,6 +179,8 @@ def main():
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--scene", default=os.path.join(ROOT, "scenes", "cbox", "cbox.xml"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip BASELINE.json configs 3-5 after the headline loop")
+    ap.add_argument("--config-steps", type=int, default=2, help="timed renders per extra configuration")
     ap.add_argument("--pool", type=int, default=0)
     ap.add_argument("--dry-launch", action="store_true", help="CPU/gloo rehearsal of the N-rank launch, reduce and report; renders nothing")
     args = ap.parse_args()
@@ -185,106 +208,133 @@ def main():
     if world > 1:
         ljdist.init_process_group("nccl")  # RCCL on ROCm
 
-    hs = lj.parse_scene(args.scene)
     ctx = lj.Context(local_rank)
-    scene = lj.Scene(ctx, hs)
-    w, h, spp = hs.width, hs.height, args.spp
-    total_samples = w * h * spp
-    frame = torch.zeros((h, w, 3), dtype=torch.float32, device=dev)
     # An explicit, non-default stream: render, reduce and the next step's clear of `frame` are then all ordered on it (the
     # reduce is enqueued on RCCL's stream behind everything this stream holds at the call, and the stream waits for it
     # before anything later).  Stream 0 would mean "the context's own stream" to lj_render_device, which nothing in torch
     # orders against.
     stream = torch.cuda.Stream(device=dev)
     assert stream.cuda_stream != 0
+    PEAK_GWINST = 1024 * 2.4 / 2   # 256 CUs x 4 SIMD-32, one wave64 instruction per 2 cycles, 2.4 GHz (MI355X_MICROARCH.md)
 
-    def step():
-        with torch.cuda.stream(stream):
-            lj.render_device(scene, frame.data_ptr(), stream=stream.cuda_stream, spp=spp, rank=rank, world_size=world, pool_paths=args.pool)
-            ljdist.reduce_framebuffer(frame, dst=0)
+    def measure(scene_xml, spp, steps, warmup):
+        """`steps` timed renders of one workload (barrier + synchronize on both sides, max over ranks), then one instrumented render
+        (flags=1: HIP events around every launch, outside the timed region) for the per-kernel durations.  Returns the line's pieces."""
+        hs = lj.parse_scene(scene_xml)
+        scene = lj.Scene(ctx, hs)
+        w, h = hs.width, hs.height
+        total_samples = w * h * spp
+        frame = torch.zeros((h, w, 3), dtype=torch.float32, device=dev)
 
-    for _ in range(args.warmup):
-        step()
-    ljdist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    ljdist.barrier()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    elapsed = ljdist.max_over_ranks(elapsed, device=dev)
-    ms_per_step = elapsed / args.steps * 1e3
-    value = total_samples * args.steps / elapsed / 1e6
-    st = scene.stats()
-    k_mean = st.bounce_iterations / max(st.samples, 1)
+        def step():
+            with torch.cuda.stream(stream):
+                lj.render_device(scene, frame.data_ptr(), stream=stream.cuda_stream, spp=spp, rank=rank, world_size=world, pool_paths=args.pool)
+                ljdist.reduce_framebuffer(frame, dst=0)
 
-    # ---- roofline of the dominant kernel: one more, instrumented, render (HIP events on the render stream around every
-    # extend / shade launch — flags=1).  Kept outside the timed region because the per-step event synchronisation
-    # perturbs it; the kernels and their inputs are identical.
-    lj.render_device(scene, frame.data_ptr(), stream=stream.cuda_stream, spp=spp, rank=rank, world_size=world, pool_paths=args.pool, flags=1)
-    torch.cuda.synchronize(dev)
-    si = scene.stats()
-    if scene.info.integrator == 6:   # volumetric path tracer: one launch per pass, a lane walks a whole path (k_volpath); timed as a whole
-        kernels = {"k_volpath": {"ms": si.render_ms, "launches": max(int(si.wavefront_steps), 1), "bytes": si.samples * 12}}
-    elif si.mega_launches > 0:   # a tiny scene: one fused persistent launch per pass (mega.hip), no path queue
-        kernels = {"k_mega": {"ms": si.mega_ms, "launches": si.mega_launches, "bytes": si.mega_bytes}}
-    else:
-        kernels = {
-            "k_extend": {"ms": si.extend_ms, "launches": si.extend_launches, "bytes": si.extend_bytes},
-            "k_shade": {"ms": si.shade_ms, "launches": si.shade_launches, "bytes": si.shade_bytes},
-        }
-    dom = max(kernels, key=lambda k: kernels[k]["ms"])
-    kd = kernels[dom]
-    avg_us = kd["ms"] * 1e3 / max(kd["launches"], 1)
-    achieved = (kd["bytes"] / max(kd["launches"], 1)) / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
-    is_default = os.path.basename(args.scene) == "cbox.xml" and spp == 256 and world == 1
-    prof, why_not = profiled_counters(dom) if is_default else (None, "only profiled for the default workload")
-    whole_gbs = (si.extend_bytes + si.shade_bytes + si.mega_bytes) / (ms_per_step * 1e-3) / 1e9
-    # `bound`: the shade kernel streams the queue (HBM).  The extend kernel is divergent BVH traversal whose queue traffic is a
-    # fraction of its time, and k_mega keeps the path state in registers (its only HBM traffic is the finished radiance): both are
-    # limited by vector-instruction issue, so their roofline is wave-instructions per second against the chip's issue peak
-    # (256 CUs x 4 SIMD-32, one wave64 instruction per 2 cycles, 2.4 GHz: MI355X_MICROARCH.md) — with the instruction count taken
-    # from this round's committed PMC pass of the same workload and the duration measured live here.  Their algorithmic HBM
-    # figure is still reported beside it (hbm_*).
-    PEAK_GWINST = 1024 * 2.4 / 2
-    hbm = {"achieved": round(achieved, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 5),
-           "frac_of_measured_copy": round(achieved / COPY_HBM_GBS, 5)}
-    roofline = {"bound": "hbm", "kernel": dom}
-    roofline.update(hbm)
-    if dom != "k_shade":
-        roofline["bound"] = "valu"
-        if prof and prof.get("valu_wave_insts"):
-            insts_per_launch = prof["valu_wave_insts"] / max(prof["launches"], 1)
-            a = insts_per_launch / (avg_us * 1e-6) / 1e9
-            roofline.update({"achieved": round(a, 1), "peak": PEAK_GWINST, "unit": "G wave-instructions/s", "frac": round(a / PEAK_GWINST, 5),
-                             "valu_active_lane_frac": prof.get("valu_active_lane_frac"), "valu_wave_insts_per_launch": int(insts_per_launch)})
-            roofline.pop("frac_of_measured_copy", None)
-            roofline["hbm_algorithmic"] = hbm
+        for _ in range(warmup):
+            step()
+        ljdist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        ljdist.barrier()
+        torch.cuda.synchronize(dev)
+        elapsed = ljdist.max_over_ranks(time.perf_counter() - t0, device=dev)
+        ms_per_step = elapsed / steps * 1e3
+        st = scene.stats()
+        lj.render_device(scene, frame.data_ptr(), stream=stream.cuda_stream, spp=spp, rank=rank, world_size=world, pool_paths=args.pool, flags=1)
+        torch.cuda.synchronize(dev)
+        si = scene.stats()
+        if scene.info.integrator == 6:   # volumetric path tracer: one launch per pass (k_volpath); timed as a whole
+            kernels = {"k_volpath": {"ms": si.render_ms, "launches": max(int(si.wavefront_steps), 1), "bytes": si.samples * 12}}
+        elif si.mega_launches > 0:   # a tiny scene: one fused persistent launch per pass (mega.hip), no path queue
+            kernels = {"k_mega": {"ms": si.mega_ms, "launches": si.mega_launches, "bytes": si.mega_bytes}}
         else:
-            roofline["note"] = "VALU-bound kernel, but no current PMC profile to take its instruction count from (%s): the figures are its algorithmic HBM rate" % why_not
-    roofline.update({"traffic": prof["traffic"] if prof else None, "traffic_source": prof["source"] if prof else why_not,
-                     "avg_launch_us": round(avg_us, 2), "algorithmic_bytes_per_launch": int(kd["bytes"] / max(kd["launches"], 1)),
-                     "all_kernels": {k: {"total_ms": round(v["ms"], 3), "launches": int(v["launches"]),
-                                         "GBps": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 2)} for k, v in kernels.items()},
-                     "whole_step_GBps": round(whole_gbs, 2), "whole_step_frac": round(whole_gbs / PEAK_HBM_GBS, 5),
-                     "whole_step_frac_of_measured_copy": round(whole_gbs / COPY_HBM_GBS, 5)})
+            kernels = {"k_extend": {"ms": si.extend_ms, "launches": si.extend_launches, "bytes": si.extend_bytes},
+                       "k_shade": {"ms": si.shade_ms, "launches": si.shade_launches, "bytes": si.shade_bytes}}
+        name = os.path.basename(scene_xml)
+        return {"hs": hs, "name": name, "spp": spp, "w": w, "h": h, "total_samples": total_samples, "ms_per_step": ms_per_step,
+                "value": total_samples * steps / elapsed / 1e6, "k_mean": st.bounce_iterations / max(st.samples, 1), "kernels": kernels, "si": si,
+                "share": si.samples / max(total_samples, 1)}   # this rank's share of the frame's samples (1 at N = 1)
+
+    def kernel_roofline(m, k, prof):
+        """One kernel of one workload against the resource that bounds it.  k_shade streams the path queue: algorithmic HBM bytes per
+        launch / live launch duration against the HBM peak.  k_extend (divergent BVH traversal), k_mega and k_volpath (paths in
+        registers) move few bytes and are limited by vector-instruction issue: wave-instructions per second against the chip's issue
+        peak, the instruction count from this round's committed PMC pass of the same workload (scaled by this rank's share of the
+        samples for N > 1), the duration measured live here.  Their algorithmic HBM figure is reported beside it."""
+        kd = m["kernels"][k]
+        avg_us = kd["ms"] * 1e3 / max(kd["launches"], 1)
+        gbs = (kd["bytes"] / max(kd["launches"], 1)) / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
+        r = {"kernel": k, "bound": "hbm", "achieved": round(gbs, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 5),
+             "avg_launch_us": round(avg_us, 2), "launches": int(kd["launches"]), "algorithmic_bytes_per_launch": int(kd["bytes"] / max(kd["launches"], 1))}
+        if k != "k_shade":
+            r["bound"] = "valu"
+            r["hbm_algorithmic"] = {"achieved": r["achieved"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": r["frac"]}
+            if prof and prof.get("valu_wave_insts") and kd["ms"] > 0:
+                insts = prof["valu_wave_insts"] * m["share"]
+                a = insts / (kd["ms"] * 1e-3) / 1e9
+                r.update({"achieved": round(a, 1), "peak": PEAK_GWINST, "unit": "G wave-instructions/s", "frac": round(a / PEAK_GWINST, 5),
+                          "valu_active_lane_frac": prof.get("valu_active_lane_frac"), "valu_wave_insts_per_render": int(insts)})
+                if prof.get("floor_wave_insts"):   # instructions the algorithm needs at full lane use (DESIGN.md section 4): distance to the floor, not utilisation
+                    r["floor_frac"] = round(prof["floor_wave_insts"] * m["share"] / (kd["ms"] * 1e-3) / 1e9 / PEAK_GWINST, 5)
+            else:
+                r["note"] = "VALU-bound kernel without a current PMC profile to take its instruction count from: the figures are its algorithmic HBM rate"
+        if prof and "fetch_bytes" in prof and "write_bytes" in prof:
+            r["traffic"] = int((prof["fetch_bytes"] + prof["write_bytes"]) * m["share"] / max(kd["launches"], 1))
+        else:
+            r["traffic"] = None
+        return r
+
+    def workload_rooflines(m):
+        profs, why = profiled_counters(f"{m['name']}@{m['spp']}")
+        out = {k: kernel_roofline(m, k, (profs or {}).get(k)) for k in m["kernels"]}
+        dom = max(m["kernels"], key=lambda k: m["kernels"][k]["ms"])
+        return dom, out, why
+
+    m = measure(args.scene, args.spp, args.steps, args.warmup)
+    dom, rl, why_not = workload_rooflines(m)
+    roofline = dict(rl[dom])
+    whole_gbs = (m["si"].extend_bytes + m["si"].shade_bytes + m["si"].mega_bytes) / (m["ms_per_step"] * 1e-3) / 1e9
+    roofline.update({"traffic_source": (profiled_counters_source() if why_not is None else why_not),
+                     "all_kernels": {k: {"total_ms": round(v["ms"], 3), "launches": int(v["launches"]), "bound": rl[k]["bound"], "frac": rl[k]["frac"]} for k, v in m["kernels"].items()},
+                     "whole_step_GBps": round(whole_gbs, 2), "whole_step_frac": round(whole_gbs / PEAK_HBM_GBS, 5)})
+
+    # ---- the other single-GPU configurations of BASELINE.json (3: disney_bsdf 256 spp, 4: veach_mi 512 spp, 5: sponza 1024 spp), a few
+    # steps each, after the headline loop and outside its timed region; same timing discipline, reported under "configs"
+    configs = []
+    is_headline = os.path.basename(args.scene) == "cbox.xml" and args.spp == 256
+    if is_headline and not args.no_configs:
+        for rel, spp_c in (("disney_bsdf_test/disney_bsdf.xml", 256), ("veach_mi/mi.xml", 512), ("sponza/sponza.xml", 1024)):
+            mc = measure(os.path.join(ROOT, "scenes", rel), spp_c, args.config_steps, 1)
+            dom_c, rl_c, why_c = workload_rooflines(mc)
+            e = {"workload": f"{mc['name']} {mc['w']}x{mc['h']} @ {spp_c} spp", "samples_per_step": mc["total_samples"], "steps": args.config_steps,
+                 "ms_per_step": round(mc["ms_per_step"], 3), "value": round(mc["value"], 2), "unit": "Msamples/s",
+                 "mean_bounce_iterations_K": round(mc["k_mean"], 4), "roofline": dict(rl_c[dom_c]),
+                 "kernels": {k: {"total_ms": round(v["ms"], 3), "bound": rl_c[k]["bound"], "achieved": rl_c[k]["achieved"], "unit": rl_c[k]["unit"], "frac": rl_c[k]["frac"],
+                                 "valu_active_lane_frac": rl_c[k].get("valu_active_lane_frac")} for k, v in mc["kernels"].items()}}
+            if why_c:
+                e["roofline"]["note"] = why_c
+            configs.append(e)
 
     if rank == 0:
-        name = os.path.basename(args.scene)
+        name, spp, w, h, hs = m["name"], m["spp"], m["w"], m["h"], m["hs"]
         out = {
             "metric": "Msamples/sec (whole node), cbox 256spp" if (name == "cbox.xml" and spp == 256) else f"Msamples/sec (whole node), {name} {spp}spp",
-            "value": round(value, 2), "unit": "Msamples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "value": round(m["value"], 2), "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(m["ms_per_step"], 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "dtype_note": "float shading against the reference's double; parity bars (tests/test_gpu_parity.py): per-sample median rel. diff < 2e-6, image L2 <= 1e-2 at 16 spp",
             "data": "scene file shipped with the reference (scenes/%s), sampleCount overridden to %d" % (os.path.relpath(args.scene, os.path.join(ROOT, "scenes")), spp),
             "config": {"workload": f"{name} {w}x{h} @ {spp} spp, path integrator" + (" (Lambertian + area light, max_depth -1, rr_depth 5)" if name == "cbox.xml" else f" (max_depth {hs.desc.options.max_depth}, rr_depth {hs.desc.options.rr_depth})"),
-                       "samples_per_step": total_samples, "mean_bounce_iterations_K": round(k_mean, 4),
+                       "samples_per_step": m["total_samples"], "mean_bounce_iterations_K": round(m["k_mean"], 4),
                        "rng": "pcg32, one stream per (pixel, sample), seed 0x853c49e6748fea9b",
                        "parallelism": f"tiles%{world}" if world > 1 else "1 GPU", "collective": "RCCL reduce(sum) of the float framebuffer" if world > 1 else "none"},
             "roofline": roofline,
         }
+        if configs:
+            out["configs"] = configs
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.scene)
         print(json.dumps(out), flush=True)

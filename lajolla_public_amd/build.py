@@ -74,6 +74,11 @@ def _same_cmd(target, cmd):
 def build_product(verbose=True):
     if os.environ.get("LJ_NO_REBUILD") and os.path.exists(LIB):   # developer A/B runs of a prebuilt LJ_VARIANT library on the GPU box
         return LIB
+    # Extra compiler flags make a VARIANT of the library (developer A/B runs).  They may only go into a library of their own
+    # (LJ_VARIANT=name -> liblajolla_hip_<name>.so) — never silently into the default one, where the next test run would load them.
+    if os.environ.get("LJ_EXTRA_HIPCC_FLAGS") and not _VARIANT and os.environ.get("LJ_VARIANT_OK") != "1":
+        raise RuntimeError("LJ_EXTRA_HIPCC_FLAGS is set without LJ_VARIANT: refusing to build the default library with variant flags "
+                           "(set LJ_VARIANT=<name> for a side-by-side library, or LJ_VARIANT_OK=1 to override)")
     os.makedirs(BUILD, exist_ok=True)
     headers = _headers()
     jobs = []

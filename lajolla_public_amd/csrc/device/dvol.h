@@ -247,6 +247,9 @@ LJ_HD f3 vol_path_sample_2(const DScene &sc, Tracer &tr, int x, int y, VolRng &r
         const float L_s1_pdf = Lt.pmf * pdf_point_on_light(sc, Lt, pl.position, pl.normal, p);
         return vdiv3(transmittance, trans_pdf) * sigma_s * (L_s1 / L_s1_pdf);
     }
+    // a ray that left the scene has no vertex to take an emission from (this arm is reached for it when sigma_t.x is 0 at the ray origin:
+    // t is then inf, or nan for u = 0, and `t < inf` fails)
+    if (!hit) return mk3(0, 0, 0);
     const f3 transmittance = vexp3(-(sigma_t * t_hit));   // (the pdf is the same expression: the ratio is 1, or 0 / 0 once it underflows)
     f3 Le = mk3(0, 0, 0);
     if (vertex.light_id >= 0) Le = light_emission(sc, sc.lights[vertex.light_id], -dir, vertex.gn);

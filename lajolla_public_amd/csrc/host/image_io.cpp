@@ -84,6 +84,7 @@ HostImage read_image(const std::string &filename, int channels) {
         std::ifstream f(filename, std::ios::binary);
         if (!f) throw LjError(LJ_ERR_IO, "cannot open image: " + filename);
         std::vector<uint8_t> bytes((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+        bytes.shrink_to_fit();   // capacity == size: a sanitizer build sees any read past the file
         HostImage rgb = decode_exr_rgb(bytes, filename);
         if (channels != 1) return rgb;
         HostImage g; g.width = rgb.width; g.height = rgb.height; g.channels = 1;
@@ -98,6 +99,7 @@ HostImage read_image(const std::string &filename, int channels) {
         std::ifstream f(filename, std::ios::binary);
         if (!f) throw LjError(LJ_ERR_IO, "cannot open image: " + filename);
         std::vector<uint8_t> bytes((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+        bytes.shrink_to_fit();   // capacity == size: a sanitizer build sees any read past the file
         int w = 0, h = 0;
         std::vector<uint8_t> y8;
         std::vector<uint8_t> rgb = decode_jpeg_rgb8(bytes, w, h, filename, channels == 1 ? &y8 : nullptr);
@@ -115,6 +117,7 @@ HostImage read_image(const std::string &filename, int channels) {
         std::ifstream f(filename, std::ios::binary);
         if (!f) throw LjError(LJ_ERR_IO, "cannot open image: " + filename);
         std::vector<uint8_t> bytes((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+        bytes.shrink_to_fit();   // capacity == size: a sanitizer build sees any read past the file
         if (ext == ".png") return read_png(bytes, filename, channels);
         if (ext == ".hdr") return read_hdr(bytes, filename, channels);
         if (ext == ".psd") return read_psd(bytes, filename, channels);

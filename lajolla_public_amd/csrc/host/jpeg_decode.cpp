@@ -284,6 +284,7 @@ std::vector<uint8_t> decode_jpeg_rgb8(const std::vector<uint8_t> &file, int &wid
             while (seg < seg_end) {
                 int pq = file[seg] >> 4, tq = file[seg] & 15; seg++;
                 if (tq > 3) throw bad("bad DQT id");
+                if (seg + (pq ? 128u : 64u) > seg_end) throw bad("DQT table runs past its segment");
                 for (int i = 0; i < 64; i++) { qt[tq][kZigzag[i]] = pq ? (uint16_t)rd16(seg) : file[seg]; seg += pq ? 2 : 1; }
                 have_qt[tq] = true;
             }
@@ -291,6 +292,7 @@ std::vector<uint8_t> decode_jpeg_rgb8(const std::vector<uint8_t> &file, int &wid
             while (seg < seg_end) {
                 int tc = file[seg] >> 4, th = file[seg] & 15; seg++;
                 if (tc > 1 || th > 3) throw bad("bad DHT id");
+                if (seg + 16 > seg_end) throw bad("DHT table runs past its segment");
                 Huff &h = tc ? hac[th] : hdc[th];
                 int total = 0; h.nsym[0] = 0;
                 for (int l = 1; l <= 16; l++) { h.nsym[l] = file[seg++]; total += h.nsym[l]; }
@@ -301,10 +303,12 @@ std::vector<uint8_t> decode_jpeg_rgb8(const std::vector<uint8_t> &file, int &wid
         } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {  // SOF0 / SOF1: sequential Huffman; SOF2: progressive Huffman
             if (!comp.empty()) throw bad("second frame header");
             progressive = m == 0xC2;
+            if (seg + 6 > seg_end) throw bad("truncated frame header");
             if (file[seg] != 8) throw LjError(LJ_ERR_UNSUPPORTED, "JPEG " + name + ": only 8-bit samples are supported");
             height = rd16(seg + 1); width = rd16(seg + 3);
             int nc = file[seg + 5];
             if (width <= 0 || height <= 0 || (nc != 1 && nc != 3 && nc != 4)) throw LjError(LJ_ERR_UNSUPPORTED, "JPEG " + name + ": unsupported component count");
+            if (seg + 6 + 3 * (size_t)nc > seg_end) throw bad("truncated frame header");
             check_image_size(width, height, n, name);
             comp.resize(nc);
             for (int i = 0; i < nc; i++) {
@@ -320,11 +324,12 @@ std::vector<uint8_t> decode_jpeg_rgb8(const std::vector<uint8_t> &file, int &wid
             }
         } else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
             throw LjError(LJ_ERR_UNSUPPORTED, "JPEG " + name + ": lossless / hierarchical / arithmetic-coded files are not supported");
-        } else if (m == 0xDD) { restart_interval = rd16(seg); }
+        } else if (m == 0xDD) { if (len < 4) throw bad("truncated DRI"); restart_interval = rd16(seg); }
         else if (m == 0xE0) { if (len >= 7 && !memcmp(&file[seg], "JFIF\0", 5)) jfif = true; }
         else if (m == 0xEE) { if (len >= 14 && !memcmp(&file[seg], "Adobe\0", 6)) app14_transform = file[seg + 11]; }
         else if (m == 0xDA) {  // SOS
             if (comp.empty()) throw bad("SOS before SOF");
+            if (seg >= seg_end) throw bad("bad scan header");
             int ns = file[seg];
             if (ns < 1 || ns > (int)comp.size() || seg + 1 + 2 * ns + 3 > seg_end) throw bad("bad scan header");
             std::vector<int> order;

@@ -15,6 +15,7 @@
 //   PIC   Softimage: a chain of 8-bit channel packets (any split of R, G, B, A), each raw, pure run-length or mixed run-length per scan line;
 //         a channel no packet carries reads 255
 // then the conversion every LDR file goes through: luma (77 R + 150 G + 29 B) >> 8 for one channel, and (float) pow(v / 255.0f, 2.2f).
+#include <cstdint>
 #include "host_scene.h"
 #include <cmath>
 #include <cstring>
@@ -152,6 +153,7 @@ HostImage read_bmp(const std::vector<uint8_t> &file, const std::string &name, in
         }
     }
     const bool bottom_up = hs > 0;
+    if (hs == INT32_MIN) throw LjError(LJ_ERR_PARSE, "BMP " + name + ": bad height");   // (-hs would overflow)
     const int h = hs < 0 ? -hs : hs;
     check_image_size(w, h, file.size(), name);
     long long psize = 0;

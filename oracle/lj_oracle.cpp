@@ -1605,7 +1605,7 @@ Spectrum vol_path_tracing_1(const OScene &scene, int x, int y, pcg32_state &rng,
 // vol_path_tracing_2 (vol_path_tracing.h:46-147): one monochromatic homogeneous medium, single scattering; free-flight sampling on
 // the red channel.  The reference reads `*vertex_` before it knows the ray hit anything (:59); for a ray that leaves the scene the
 // cross sections are looked up at the ray origin here (a homogeneous medium — the only kind this version is meant for — has no
-// position dependence), and the `t >= t_hit` arm cannot be reached then (t_hit is infinite).
+// position dependence); the `t >= t_hit` arm is reached by such a ray only when sigma_t.x is 0 there, and returns zero.
 Spectrum vol_path_tracing_2(const OScene &scene, int x, int y, pcg32_state &rng, Counters *cnt) {
     const LjCamera &cam = scene.d.camera;
     Real jy = next_pcg32_real(rng);
@@ -1643,6 +1643,9 @@ Spectrum vol_path_tracing_2(const OScene &scene, int x, int y, pcg32_state &rng,
         const Real L_s1_pdf = scene.light_dist.pmf[light_id] * pdf_point_on_light(scene, light_id, pl, p);
         return vmul(vmul(vdiv(transmittance, trans_pdf), sigma_s), L_s1 / L_s1_pdf);
     }
+    // A ray that left the scene reaches this arm when sigma_t.x is 0 at its origin (t is then inf, or nan for u = 0): the reference would
+    // read its empty optional here; there is no vertex to take an emission from, so the sample is zero.
+    if (!hit) return {0, 0, 0};
     const Spectrum transmittance = vexp(-(sigma_t * t_hit));   // (trans_pdf is the same expression: the ratio is 1, or 0/0 once it underflows)
     Spectrum Le{0, 0, 0};
     if (scene.shapes[vertex.shape_id].area_light_id >= 0) Le = vertex_emission(scene, vertex, -ray.dir);

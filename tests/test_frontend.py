@@ -315,6 +315,22 @@ def test_unsupported_and_broken_images_fail_loudly(tmp_path):
     assert e.value.code == _abi.LJ_ERR_IO
 
 
+def test_jpeg_segments_shorter_than_their_payload_are_refused(tmp_path):
+    """A DQT / DHT / SOF / DRI / SOS segment whose declared length is shorter than what its parser reads, at the end of the file, must be a
+    parse error, not a read past the buffer (round-2 advisor: FF D8 FF DB 00 03 00 read 64 bytes beyond a 7-byte file)."""
+    soi = b"\xff\xd8"
+    cases = {"dqt7": soi + b"\xff\xdb\x00\x03\x00", "dqt16": soi + b"\xff\xdb\x00\x05\x10\x01\x02", "dht": soi + b"\xff\xc4\x00\x04\x00\x01",
+             "dht_syms": soi + b"\xff\xc4\x00\x14\x00" + b"\x10" * 16 + b"\x00", "sof6": soi + b"\xff\xc0\x00\x04\x08\x00",
+             "sof_comps": soi + b"\xff\xc0\x00\x08\x08\x00\x08\x00\x08\x03", "dri": soi + b"\xff\xdd\x00\x02",
+             "sos": soi + b"\xff\xc0\x00\x0b\x08\x00\x08\x00\x08\x01\x01\x11\x00" + b"\xff\xda\x00\x02"}
+    for name, payload in cases.items():
+        p = tmp_path / (name + ".jpg")
+        p.write_bytes(payload)
+        with pytest.raises(lj.LajollaError) as e:
+            lj.read_image(str(p), 3)
+        assert e.value.code in (_abi.LJ_ERR_PARSE, _abi.LJ_ERR_UNSUPPORTED), name
+
+
 def test_image_headers_that_do_not_fit_their_file_are_refused(tmp_path):
     """A header may claim any size; nothing is allocated for one the file could not possibly hold (found by tools/fuzz_decoders.sh: a damaged
     BMP asked for 1.5 TB)."""

@@ -79,6 +79,26 @@ def test_versions_one_and_two_are_estimators_of_their_own():
         check_samples(pt, Oracle(hs).render(spp=8, crop=crop, per_sample=True)[2])
 
 
+def test_version_two_with_an_empty_medium_and_rays_that_leave_the_scene():
+    """sigma_t = 0 at the camera makes the free-flight distance infinite (nan for u = 0), so a camera ray that misses everything falls
+    through to the surface arm of vol_path_tracing_2 without a vertex (round-2 advisor: the device read an uninitialised light id there).
+    Such a sample is zero — in the oracle and in the host build of the device code alike; rays that do hit are unaffected."""
+    hs = vol_scene("volpath_test2")
+    m = hs.desc.media[hs.desc.camera.medium_id]
+    for k in range(3):
+        m.sigma_a[k] = 0.0; m.sigma_s[k] = 0.0
+    crop = (0, 0, 48, 48)     # a corner of the frame: rays there pass the scene's only object
+    o, tw = Oracle(hs), Twin(hs)
+    rc, _, ps, _ = o.render(spp=4, crop=crop, per_sample=True)
+    pt, _ = tw.render_samples(crop, 4)
+    assert rc == 0 and np.isfinite(pt).all() and np.isfinite(ps).all()
+    assert not ps.any() and not pt.any()
+    mid = (224, 224, 256, 256)   # rays that hit the emitter: its radiance, unattenuated
+    rc, _, ps2, _ = o.render(spp=4, crop=mid, per_sample=True)
+    pt2, _ = tw.render_samples(mid, 4)
+    assert rc == 0 and ps2.any() and np.allclose(pt2, ps2, rtol=1e-5, atol=1e-7)
+
+
 @pytest.mark.parametrize("name,crop", CASES)
 def test_device_code_follows_the_oracle(name, crop):
     hs = vol_scene(name)
