@@ -487,7 +487,7 @@ int lj_scene_upload(lj_context *ctx, const LjSceneDesc *desc, lj_scene **out) {
         d.nodes = (const ljd::DNode4 *)sc->nodes.p; d.nodes8 = (const ljd::DNode8 *)sc->nodes8.p; d.node8_stride = node8_stride; d.leaf_prims = (const ljd::DPrim *)sc->leaf_prims.p; d.prims = (const ljd::DPrimShade *)sc->prims.p;
         d.spheres = (const ljd::DSphere *)sc->spheres.p; d.materials = (const ljd::DMaterial *)sc->materials.p; d.lights = (const ljd::DLight *)sc->lights.p;
         d.light_cdf = (const float *)sc->light_cdf.p; d.light_tris = (const ljd::DLightTri *)sc->light_tris.p; d.light_tri_cdf = (const float *)sc->light_tri_cdf.p;
-        d.images3 = (const ljd::DImage *)sc->images3.p; d.images1 = (const ljd::DImage *)sc->images1.p; d.texels = (const float *)sc->texels.p; d.env_tables = (const float *)sc->env_tables.p;
+        d.images3 = (const ljd::DImage *)sc->images3.p; d.images1 = (const ljd::DImage *)sc->images1.p; d.texels = (const float *)sc->texels.p; d.env_tables = (const float *)sc->env_tables.p; d.env_marg = d.env_tables + F.env_marg_first;
         d.media = (const ljd::DMedium *)sc->media.p; d.volume_data = (const float *)sc->volume_data.p; d.shape_media = (const int32_t *)sc->shape_media.p;
         d.scan_leaves = F.scan_leaves.empty() ? nullptr : (const ljd::DScanLeaf *)sc->scan_leaves.p;
         sc->dscene = d;
@@ -500,7 +500,7 @@ int lj_scene_upload(lj_context *ctx, const LjSceneDesc *desc, lj_scene **out) {
         sc->ecfg = ljd::extend_config((int)F.nodes.size(), (int)F.leaf_prims.size(), F.bvh_depth, (int)F.n_spheres, (int)F.nodes8.size(), F.bvh8_depth);
         if (const char *e = getenv("LJ_TUNE_REFILL")) sc->ecfg.refill_min = (uint32_t)atoi(e);
         if (const char *e = getenv("LJ_TUNE_MINDESC")) sc->ecfg.min_descending = (uint32_t)atoi(e);
-        sc->scfg = ljd::shade_config(F.prims.size(), F.materials.size(), F.lights.size(), F.light_tris.size(), F.light_tri_cdf.size());
+        sc->scfg = ljd::shade_config(F.prims.size(), F.materials.size(), F.lights.size(), F.light_tris.size(), F.light_tri_cdf.size(), F.images3.size(), F.images1.size(), (size_t)F.env_marg_count);
         {   // which Material / Texture / Light alternatives the scene holds decides the shade kernel instantiation
             uint32_t kinds = 0; bool textured = false, sphere_lights = false;
             for (const auto &m : F.materials) { kinds |= 1u << m.kind; for (int t = 0; t < 12; t++) textured = textured || m.tex[t].kind != 0; }

@@ -15,7 +15,7 @@
 #include <vector>
 
 namespace ljd {
-ShadeConfig shade_config(size_t n_prims, size_t n_materials, size_t n_lights, size_t n_light_tris, size_t n_light_tri_cdf);
+ShadeConfig shade_config(size_t n_prims, size_t n_materials, size_t n_lights, size_t n_light_tris, size_t n_light_tri_cdf, size_t n_images3, size_t n_images1, size_t n_env_marg);
 int shade_variant(uint32_t kinds, bool textured, bool envmap, bool sphere_lights);
 ExtendConfig extend_config(int n_nodes, int n_prims, int bvh_depth, int n_spheres, int n_nodes8, int bvh8_depth);
 int max_stack_depth();

@@ -16,6 +16,6 @@ struct ExtendConfig {
     int wide; int stack8; int lds_nodes8; size_t smem8;
 };
 // LDS staging plan of the shade kernel (sizes rounded up to 16 bytes) and the feature-set instantiation (dshade.h)
-struct ShadeConfig { uint32_t prims_bytes, materials_bytes, lights_bytes, light_cdf_bytes, light_tris_bytes, light_tri_cdf_bytes, stage_prims; int variant; size_t smem; };
+struct ShadeConfig { uint32_t prims_bytes, materials_bytes, lights_bytes, light_cdf_bytes, light_tris_bytes, light_tri_cdf_bytes, stage_prims, images3_bytes, images1_bytes, env_marg_bytes; int variant; size_t smem; };
 
 } // namespace ljd

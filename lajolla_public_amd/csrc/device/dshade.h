@@ -150,6 +150,49 @@ LJ_HD int sample_cdf(const float *cdf, int n, float u) {
     return off < 0 ? 0 : (off > n - 1 ? n - 1 : off);
 }
 
+// The same search with a guide table: entry b of `guide` (n entries, one per 1/n of the unit interval, built on the host: flatten.cpp
+// make_cdf_guide) brackets the answer for every u whose bin is b — low 16 bits: first candidate, high 16 bits: last — so the bisection
+// runs over a handful of entries instead of all n + 1: an environment map's two searches are 21 dependent loads otherwise, the longest
+// latency chain of a shade step.  Same comparisons on the same floats: the same index as sample_cdf, always.
+LJ_HD int sample_cdf_guided(const float *cdf, const float *guide, int n, float u) {
+    int b = (int)(u * (float)n);
+    b = b < 0 ? 0 : (b > n - 1 ? n - 1 : b);
+    union { float f; uint32_t u; } g; g.f = guide[b];
+    int lo = (int)(g.u & 0xffffu), hi = (int)(g.u >> 16);
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (cdf[mid] > u) hi = mid; else lo = mid + 1; }
+    int off = lo - 1;
+    return off < 0 ? 0 : (off > n - 1 ? n - 1 : off);
+}
+// ... returning cdf[off] and cdf[off + 1] as well (what inverting the piecewise-linear cdf needs next).  A bracket of at most four entries —
+// the usual case — is fetched at once with its two neighbours: six independent loads and a count instead of bisection steps that each
+// wait for the one before, and the two values come out of the same six.
+LJ_HD int sample_cdf_guided(const float *cdf, const float *guide, int n, float u, float &c0, float &c1) {
+    int b = (int)(u * (float)n);
+    b = b < 0 ? 0 : (b > n - 1 ? n - 1 : b);
+    union { float f; uint32_t u; } g; g.f = guide[b];
+    int lo = (int)(g.u & 0xffffu), hi = (int)(g.u >> 16);
+    if (hi - lo <= 4) {
+        float v[6];
+        for (int k = 0; k < 6; k++) { int i = lo - 1 + k; i = i < 0 ? 0 : (i > n ? n : i); v[k] = cdf[i]; }
+        int r = lo;   // the first entry greater than u = lo + the entries of [lo, hi) that are not (the cdf is non-decreasing)
+        for (int k = 1; k <= 4; k++) r += (lo - 1 + k < hi && v[k] <= u) ? 1 : 0;
+        const int off = r - 1;
+        if (off >= 0 && off <= n - 1) {
+            const int k0 = off - (lo - 1);   // 0 .. 4
+            c0 = k0 == 0 ? v[0] : (k0 == 1 ? v[1] : (k0 == 2 ? v[2] : (k0 == 3 ? v[3] : v[4])));
+            c1 = k0 == 0 ? v[1] : (k0 == 1 ? v[2] : (k0 == 2 ? v[3] : (k0 == 3 ? v[4] : v[5])));
+            return off;
+        }
+        lo = r;   // (clamped below)
+    } else {
+        while (lo < hi) { int mid = (lo + hi) >> 1; if (cdf[mid] > u) hi = mid; else lo = mid + 1; }
+    }
+    int off = lo - 1;
+    off = off < 0 ? 0 : (off > n - 1 ? n - 1 : off);
+    c0 = cdf[off]; c1 = cdf[off + 1];
+    return off;
+}
+
 // ------------------------------------------------------------------ path vertex (intersection.cpp:38-62)
 struct DVertex {
     f3 position, gn;
@@ -300,14 +343,15 @@ LJ_HD LightSample sample_point_on_light(const DScene &sc, const DLight &L, f3 re
             ls.normal = mk3((float)nx, (float)ny, (float)nz);
         }
     } else {  // envmap.inl:7-20 with table_dist.cpp:116-139
-        const float *cm = sc.env_tables + L.env_cdf_marg;
-        int yo = sample_cdf(cm, L.env_h, u1);
-        float dy = u1 - cm[yo];
-        if (cm[yo + 1] - cm[yo] > 0.0f) dy /= (cm[yo + 1] - cm[yo]);
+        const float *cm = sc.env_marg + (L.env_cdf_marg - sc.env_marg_first);
+        float c0, c1;
+        int yo = sample_cdf_guided(cm, sc.env_marg + (L.env_guide_marg - sc.env_marg_first), L.env_h, u1, c0, c1);
+        float dy = u1 - c0;
+        if (c1 - c0 > 0.0f) dy /= (c1 - c0);
         const float *cdf = sc.env_tables + L.env_cdf_rows + (int64_t)yo * (L.env_w + 1);
-        int xo = sample_cdf(cdf, L.env_w, u0);
-        float dx = u0 - cdf[xo];
-        if (cdf[xo + 1] - cdf[xo] > 0.0f) dx /= (cdf[xo + 1] - cdf[xo]);
+        int xo = sample_cdf_guided(cdf, sc.env_tables + L.env_guide_rows + (int64_t)yo * L.env_w, L.env_w, u0, c0, c1);
+        float dx = u0 - c0;
+        if (c1 - c0 > 0.0f) dx /= (c1 - c0);
         float az = ((xo + dx) / L.env_w) * kTwoPi, el = ((yo + dy) / L.env_h) * kPi;
         f3 local = mk3(sinf(az) * sinf(el), cosf(el), -cosf(az) * sinf(el));
         ls.position = mk3(0, 0, 0); ls.normal = -xform_vector9(L.to_world, local);
@@ -340,7 +384,7 @@ LJ_HD float pdf_point_on_light(const DScene &sc, const DLight &L, f3 pos, f3 nrm
     float cos_el = local.y, sin_el = sqrtf(clampf(1.0f - cos_el * cos_el, 0.0f, 1.0f));
     if (sin_el <= 0.0f) return 0.0f;
     int x = (int)clampf(u * L.env_w, 0.0f, (float)(L.env_w - 1)), y = (int)clampf(v * L.env_h, 0.0f, (float)(L.env_h - 1));
-    float pdf = sc.env_tables[L.env_pdf_marg + y] * sc.env_tables[L.env_pdf_rows + (int64_t)y * L.env_w + x] * L.env_w * L.env_h;
+    float pdf = sc.env_marg[L.env_pdf_marg - sc.env_marg_first + y] * sc.env_tables[L.env_pdf_rows + (int64_t)y * L.env_w + x] * L.env_w * L.env_h;
     return pdf / (2.0f * kPi * kPi * sin_el);
 }
 

@@ -23,7 +23,15 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 // The shading tables every path touches in a data-dependent order (per-primitive shading records, materials, lights
 // and their cdfs) are copied to LDS once per workgroup when they fit: a chain of five or six dependent L2-latency
 // gathers per path-step becomes LDS-latency reads.  Pointers stay generic, so dshade.h is unchanged.
-struct ShadeStage { uint32_t prims_bytes, materials_bytes, lights_bytes, light_cdf_bytes, light_tris_bytes, light_tri_cdf_bytes, stage_prims; };
+// (and, when they fit beside those: the image descriptors every texture lookup starts from and the environment map's marginal tables)
+struct ShadeStage { uint32_t prims_bytes, materials_bytes, lights_bytes, light_cdf_bytes, light_tris_bytes, light_tri_cdf_bytes, stage_prims, images3_bytes, images1_bytes, env_marg_bytes; };
+inline ShadeStage make_shade_stage(const ShadeConfig &c) {
+    ShadeStage st;
+    st.prims_bytes = c.prims_bytes; st.materials_bytes = c.materials_bytes; st.lights_bytes = c.lights_bytes; st.light_cdf_bytes = c.light_cdf_bytes;
+    st.light_tris_bytes = c.light_tris_bytes; st.light_tri_cdf_bytes = c.light_tri_cdf_bytes; st.stage_prims = c.stage_prims;
+    st.images3_bytes = c.images3_bytes; st.images1_bytes = c.images1_bytes; st.env_marg_bytes = c.env_marg_bytes;
+    return st;
+}
 
 __device__ __forceinline__ void lds_copy16(void *dst, const void *src, uint32_t bytes) {
     const v4f *s4 = (const v4f *)src; v4f *d4 = (v4f *)dst;
@@ -44,7 +52,10 @@ __device__ __forceinline__ void stage_shade_tables(DScene &sc, const ShadeStage 
     lds_copy16(p, sc.lights, stg.lights_bytes); sc.lights = (const DLight *)p; p += stg.lights_bytes;
     lds_copy16(p, sc.light_cdf, stg.light_cdf_bytes); sc.light_cdf = (const float *)p; p += stg.light_cdf_bytes;
     lds_copy16(p, sc.light_tris, stg.light_tris_bytes); sc.light_tris = (const DLightTri *)p; p += stg.light_tris_bytes;
-    lds_copy16(p, sc.light_tri_cdf, stg.light_tri_cdf_bytes); sc.light_tri_cdf = (const float *)p;
+    lds_copy16(p, sc.light_tri_cdf, stg.light_tri_cdf_bytes); sc.light_tri_cdf = (const float *)p; p += stg.light_tri_cdf_bytes;
+    if (stg.images3_bytes) { lds_copy16(p, sc.images3, stg.images3_bytes); sc.images3 = (const DImage *)p; p += stg.images3_bytes; }
+    if (stg.images1_bytes) { lds_copy16(p, sc.images1, stg.images1_bytes); sc.images1 = (const DImage *)p; p += stg.images1_bytes; }
+    if (stg.env_marg_bytes) { lds_copy16(p, sc.env_marg, stg.env_marg_bytes); sc.env_marg = (const float *)p; }
 }
 
 } // namespace ljd

@@ -106,6 +106,7 @@ struct DLight {
     float to_world[9], to_local[9];   // upper-left 3x3, row-major
     float scale;
     int32_t env_w, env_h, env_cdf_rows, env_pdf_rows, env_cdf_marg, env_pdf_marg;  // offsets into env_tables
+    int32_t env_guide_rows, env_guide_marg;   // guide tables of the two cdf searches (dshade.h sample_cdf_guided): env_h x env_w and env_h entries, bit patterns
     DTexture values;
 };
 
@@ -152,6 +153,10 @@ struct DScene {
     const DImage *images3, *images1;
     const float *texels;
     const float *env_tables;
+    // the environment map's marginal tables (cdf, pdf and the cdf's guide: 3 h + 1 floats, contiguous from env_tables[env_marg_first]) are
+    // read through this pointer, which the shade kernels redirect to an LDS copy: offsets into env_tables minus env_marg_first index it
+    const float *env_marg; int32_t env_marg_first, env_marg_count;
+    int32_t n_images3, n_images1;
     int32_t envmap_light_id;
     int32_t max_depth, rr_depth;
     float eps;                       // get_shadow_epsilon == get_intersection_epsilon (scene.h:99-105)

@@ -437,14 +437,62 @@ __global__ void __launch_bounds__(kBlock, (RESIDENT && !SPHERES && !STATS) ? LJ_
 }
 
 // ---------------------------------------------------------------- shade + compaction
+// What a path will do in this shade step, as far as its queue records tell — the key its chunk is sorted by before shading (below):
+// 0 nothing (no extension ray was traced: only the pending next-event estimate is added), 1 its ray left the scene (environment map),
+// 2 it only accounts for the hit (Russian roulette ended it), 3 + k full shading on Material alternative k (material.h:102-110).
+constexpr int kShadeKeys = 12;
+template <class Ft>
+__device__ __forceinline__ int shade_key(const DScene &sc, const DQueue &q, uint32_t slot) {
+    const uint32_t flags = f2u(q.rd[slot].w);
+    if (flags & PF_NO_EXT) return 0;
+    const int gprim = (int)(f2u(q.rh[slot].w) & 0x3fffffffu) - 1;
+    if (gprim < 0) return 1;
+    if (flags & PF_DYING) return 2;
+    return 3 + sc.materials[sc.prims[gprim].material_id].kind;
+}
+// Scenes with several Material alternatives or an environment map: the lanes of a wave would each take another branch of shade_path
+// (disney_bsdf.xml: 42 % of lanes active per instruction).  Such a feature set sorts every 256-path chunk by shade_key first.
+template <class Ft> struct ShadeSorted { static constexpr bool value = Ft::envmap || (Ft::kinds & (Ft::kinds - 1u)) != 0u; };
+
 // Shade the `count` live paths at the front of one segment chunk by chunk; survivors are compacted to the front, in
 // order (stable).  Returns the number of survivors (identical in every thread).  s_wcnt: 2 x (kBlock / 64) words of LDS.
+// Sorted feature sets: within a chunk, thread t takes the t-th path in (key, slot) order — a counting sort by wave ballots, one LDS
+// table of counts and one of slots — so that a wave's lanes run the same branch of shade_path; the survivors are then compacted in that
+// order.  A path's value does not depend on where it sits in the queue (its radiance goes to sample_rgb[sample]), so images are unchanged.
 template <class Ft>
 __device__ __forceinline__ uint32_t shade_compact_segment(const DScene &sc, const DPass &pass, const DQueue &q, uint32_t base, uint32_t count, ShadeCounters &cnt, uint32_t (*s_wcnt)[kBlock / 64]) {
+    constexpr bool SORT = ShadeSorted<Ft>::value;
+    __shared__ uint16_t s_perm[SORT ? kBlock : 1];
+    __shared__ uint16_t s_kcnt[SORT ? kShadeKeys : 1][kBlock / 64];
     const uint32_t wave = threadIdx.x >> 6;
     uint32_t out = 0;  // survivors written so far (identical in every thread)
     for (uint32_t c0 = 0, it = 0; c0 < count; c0 += kBlock, it++) {
-        const uint32_t j = c0 + threadIdx.x;
+        uint32_t j = c0 + threadIdx.x;
+        if (SORT) {
+            const int key = j < count ? shade_key<Ft>(sc, q, base + j) : kShadeKeys;   // (slots beyond the live front sort last)
+            uint32_t rank_in_key = 0;
+#pragma unroll
+            for (int k = 0; k < kShadeKeys; k++) {
+                if (k >= 3 && !Ft::kind(k - 3)) continue;
+                if (k == 1 && !Ft::envmap) { /* misses still exist without an environment map: they end the path */ }
+                const unsigned long long m = __ballot(key == k);
+                if (key == k) rank_in_key = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if ((threadIdx.x & 63) == 0) s_kcnt[k][wave] = (uint16_t)__popcll(m);
+            }
+            __syncthreads();
+            if (key < kShadeKeys) {
+                uint32_t pos = rank_in_key;
+#pragma unroll
+                for (int k = 0; k < kShadeKeys; k++) {
+                    if (k >= 3 && !Ft::kind(k - 3)) continue;
+                    for (uint32_t w = 0; w < kBlock / 64; w++) { const uint32_t n = s_kcnt[k][w]; pos += (k < key || (k == key && w < wave)) ? n : 0u; }
+                }
+                s_perm[pos] = (uint16_t)threadIdx.x;
+            }
+            __syncthreads();
+            const uint32_t live = count - c0 < kBlock ? count - c0 : kBlock;
+            j = threadIdx.x < live ? c0 + s_perm[threadIdx.x] : count;
+        }
         bool alive = false;
         PathState ps;
         if (j < count) {
@@ -798,7 +846,7 @@ ExtendConfig extend_config(int n_nodes, int n_prims, int bvh_depth, int n_sphere
 int max_stack_depth() { return 40; }  // inner levels; the builder's own cap is 38
 
 // LDS staging plan of the shade kernel; sizes are rounded up to 16 bytes (the device buffers are padded accordingly).
-ShadeConfig shade_config(size_t n_prims, size_t n_materials, size_t n_lights, size_t n_light_tris, size_t n_light_tri_cdf) {
+ShadeConfig shade_config(size_t n_prims, size_t n_materials, size_t n_lights, size_t n_light_tris, size_t n_light_tri_cdf, size_t n_images3, size_t n_images1, size_t n_env_marg) {
     auto r16 = [](size_t b) { return (uint32_t)((b + 15) & ~(size_t)15); };
     ShadeConfig c{};
     c.variant = kShadeVariantAll;
@@ -812,6 +860,13 @@ ShadeConfig shade_config(size_t n_prims, size_t n_materials, size_t n_lights, si
     c.stage_prims = (small + c.prims_bytes <= 32 * 1024) ? 1u : 0u;
     if (!c.stage_prims) c.prims_bytes = 0;
     c.smem = small + c.prims_bytes;
+    // beside those, while they stay small: the image descriptors (the first, dependent, load of every texture lookup) and the
+    // environment map's marginal cdf / pdf / guide (its first search then never leaves the CU)
+    const uint32_t img3 = r16(n_images3 * sizeof(DImage)), img1 = r16(n_images1 * sizeof(DImage)), marg = r16(n_env_marg * 4);
+    if (!(getenv("LJ_TUNE_STAGE_IMAGES") && atoi(getenv("LJ_TUNE_STAGE_IMAGES")) == 0)) {
+        if (img3 + img1 <= 8 * 1024) { c.images3_bytes = img3; c.images1_bytes = img1; c.smem += img3 + img1; }
+        if (n_env_marg > 0 && marg <= 8 * 1024) { c.env_marg_bytes = marg; c.smem += marg; }
+    }
     return c;
 }
 
@@ -842,9 +897,7 @@ int shade_variant(uint32_t kinds, bool textured, bool envmap, bool sphere_lights
 }
 
 void launch_shade(const DScene &sc, const DPass &pass, const DQueue &q, DBlockState *blocks, uint32_t n_blocks, uint32_t seg, const ShadeConfig &cfg, uint32_t *work, uint32_t *chunk_list, uint32_t parity, uint32_t extend_waves, hipStream_t s) {
-    ShadeStage st;
-    st.prims_bytes = cfg.prims_bytes; st.materials_bytes = cfg.materials_bytes; st.lights_bytes = cfg.lights_bytes; st.light_cdf_bytes = cfg.light_cdf_bytes;
-    st.light_tris_bytes = cfg.light_tris_bytes; st.light_tri_cdf_bytes = cfg.light_tri_cdf_bytes; st.stage_prims = cfg.stage_prims;
+    const ShadeStage st = make_shade_stage(cfg);
     auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(n_blocks), dim3(kBlock), cfg.smem, s, sc, pass, q, blocks, seg, st, work, chunk_list, parity, extend_waves); };
     // (a scene whose tables are not staged at all runs the all-features instantiation: lj_scene_upload picks it)
     const int stage = cfg.smem == 0 ? 0 : (cfg.stage_prims ? 2 : 1);
@@ -860,9 +913,7 @@ size_t tail_smem(const ExtendConfig &ecfg, const ShadeConfig &scfg) {
     return total <= 64 * 1024 ? total : 0;
 }
 void launch_tail(const DScene &sc, const DPass &pass, const DQueue &q, DBlockState *blocks, uint32_t n_blocks, uint32_t seg, const ExtendConfig &ecfg, const ShadeConfig &scfg, int *spill, hipStream_t s) {
-    ShadeStage st;
-    st.prims_bytes = scfg.prims_bytes; st.materials_bytes = scfg.materials_bytes; st.lights_bytes = scfg.lights_bytes; st.light_cdf_bytes = scfg.light_cdf_bytes;
-    st.light_tris_bytes = scfg.light_tris_bytes; st.light_tri_cdf_bytes = scfg.light_tri_cdf_bytes; st.stage_prims = scfg.stage_prims;
+    const ShadeStage st = make_shade_stage(scfg);
     const uint32_t at = (uint32_t)((ecfg.smem + 15) & ~(size_t)15);
     const size_t smem = tail_smem(ecfg, scfg);
     auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(n_blocks), dim3(kBlock), smem, s, sc, pass, q, blocks, seg, st, at, ecfg.stack, ecfg.lds_nodes, ecfg.lds_prims, spill); };

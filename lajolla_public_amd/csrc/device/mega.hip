@@ -332,9 +332,7 @@ int mega_blocks_per_cu(const ShadeConfig &scfg) { return scfg.variant == 0 ? LJ_
 
 void launch_mega(const DScene &sc, const DPass &pass, const ShadeConfig &scfg, bool spheres, uint32_t n_samples, uint32_t grab, uint32_t *sample_counter,
                  unsigned long long *stats, int grid, hipStream_t s) {
-    ShadeStage st;
-    st.prims_bytes = scfg.prims_bytes; st.materials_bytes = scfg.materials_bytes; st.lights_bytes = scfg.lights_bytes; st.light_cdf_bytes = scfg.light_cdf_bytes;
-    st.light_tris_bytes = scfg.light_tris_bytes; st.light_tri_cdf_bytes = scfg.light_tri_cdf_bytes; st.stage_prims = scfg.stage_prims;
+    const ShadeStage st = make_shade_stage(scfg);
     const uint32_t at = (uint32_t)((scfg.smem + 15) & ~(size_t)15);
     const size_t smem = mega_smem(sc, scfg);
     with_shade_variant(scfg.variant, [&](auto ft) {

@@ -30,6 +30,20 @@ void table_1d(const std::vector<double> &f, std::vector<double> &pmf, std::vecto
     else { for (size_t i = 0; i < n; i++) { pmf[i] = 1.0 / (double)n; cdf[i] = (double)i / (double)n; } cdf.back() = 1; }
 }
 
+// guide table of sample_cdf_guided (device/dshade.h) for a cdf of n + 1 float entries: for bin b (u * n truncates to b) the index the full
+// search returns — the first entry greater than u, or n + 1 — lies between the results for (b - 1) / n and (b + 2) / n: one bin of slack
+// on either side covers the rounding of u * n and of b / n in float.  Packed lo | hi << 16, stored as a float bit pattern.
+void make_cdf_guide(const float *cdf, int n, std::vector<float> &out) {
+    if (n + 1 > 0xffff) throw LjError(LJ_ERR_UNSUPPORTED, "environment map wider or taller than 65534 texels");
+    auto upper = [&](float u) { int lo = 0, hi = n + 1; while (lo < hi) { int mid = (lo + hi) >> 1; if (cdf[mid] > u) hi = mid; else lo = mid + 1; } return lo; };
+    for (int b = 0; b < n; b++) {
+        const uint32_t lo = b >= 1 ? (uint32_t)upper((float)(b - 1) / (float)n) : 0u;
+        const uint32_t hi = b + 2 <= n - 1 ? (uint32_t)upper((float)(b + 2) / (float)n) : (uint32_t)(n + 1);
+        union { uint32_t u; float f; } c; c.u = lo | (hi << 16);
+        out.push_back(c.f);
+    }
+}
+
 ljd::DTexture conv_tex(const LjTexture &t) {
     ljd::DTexture d{};
     d.kind = t.kind; d.texture_id = t.texture_id;
@@ -80,6 +94,8 @@ ljd::DScene FlatScene::host_view() const {
     s.lights = lights.data(); s.n_lights = (int)lights.size();
     s.light_cdf = light_cdf.data(); s.light_tris = light_tris.data(); s.light_tri_cdf = light_tri_cdf.data();
     s.images3 = images3.data(); s.images1 = images1.data(); s.texels = texels.data(); s.env_tables = env_tables.data();
+    s.env_marg = env_tables.data() + env_marg_first; s.env_marg_first = env_marg_first; s.env_marg_count = env_marg_count;
+    s.n_images3 = (int32_t)images3.size(); s.n_images1 = (int32_t)images1.size();
     s.envmap_light_id = envmap_light_id; s.max_depth = max_depth; s.rr_depth = rr_depth;
     s.eps = (float)shadow_epsilon;
     s.init_spread = 0.25f / (float)std::max(cam.width, cam.height);
@@ -354,7 +370,17 @@ FlatScene flatten_scene(const LjSceneDesc &d) {
             for (int y = 0; y < h; y++) cdf_rows[(size_t)y * (w + 1) + w] = 1;
             dl.env_w = w; dl.env_h = h;
             auto push = [&](const std::vector<double> &v) { int off = (int)F.env_tables.size(); for (double x : v) F.env_tables.push_back((float)x); return off; };
-            dl.env_cdf_rows = push(cdf_rows); dl.env_pdf_rows = push(pdf_rows); dl.env_cdf_marg = push(cdf_marg); dl.env_pdf_marg = push(pdf_marg);
+            dl.env_cdf_rows = push(cdf_rows); dl.env_pdf_rows = push(pdf_rows);
+            // guide tables over the float tables the device searches
+            dl.env_guide_rows = (int)F.env_tables.size();
+            for (int y = 0; y < h; y++) { std::vector<float> g; make_cdf_guide(&F.env_tables[dl.env_cdf_rows + (size_t)y * (w + 1)], w, g); F.env_tables.insert(F.env_tables.end(), g.begin(), g.end()); }
+            // the marginal tables, contiguous and 16-byte aligned: the shade kernels keep a copy of them in LDS
+            while (F.env_tables.size() % 4) F.env_tables.push_back(0.0f);
+            F.env_marg_first = (int)F.env_tables.size();
+            dl.env_cdf_marg = push(cdf_marg); dl.env_pdf_marg = push(pdf_marg);
+            dl.env_guide_marg = (int)F.env_tables.size();
+            { std::vector<float> g; make_cdf_guide(&F.env_tables[dl.env_cdf_marg], h, g); F.env_tables.insert(F.env_tables.end(), g.begin(), g.end()); }
+            F.env_marg_count = (int)F.env_tables.size() - F.env_marg_first;
             power[li] = kPi * F.bounds_radius * F.bounds_radius * total / ((double)w * h);  // envmap.inl:1-5
         }
         F.lights.push_back(dl);

@@ -24,6 +24,7 @@ struct FlatScene {
     std::vector<ljd::DImage> images3, images1;
     std::vector<float> texels;
     std::vector<float> env_tables;
+    int env_marg_first = 0, env_marg_count = 0;   // the environment map's marginal tables inside env_tables (dtypes.h DScene::env_marg)
     std::vector<ljd::DMedium> media;
     std::vector<float> volume_data;
     std::vector<int32_t> shape_media;

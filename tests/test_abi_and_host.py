@@ -105,6 +105,16 @@ def test_bvh_traversal_equals_brute_force(name):
         assert np.array_equal(ho[f].view(np.uint32), hb[f].view(np.uint32)), f
 
 
+def test_guided_cdf_search_is_the_full_search():
+    """An environment map's two table searches (table_dist.cpp:116-139) run over a guide-table bracket on the device (dshade.h
+    sample_cdf_guided); it must return the index of the full bisection for every u — random ones, every bin edge, every cdf value."""
+    import ctypes as C
+    hs = lj.parse_scene(scene_path("disney_bsdf"))
+    tw = Twin(hs)
+    tw.lib.twin_cdf_guide_mismatches.restype = C.c_longlong
+    assert tw.lib.twin_cdf_guide_mismatches(tw.h, C.c_int(20000)) == 0
+
+
 def test_unsupported_variants_fail_loudly():
     """Anything the device path does not implement must raise LJ_ERR_UNSUPPORTED at upload, never fall back."""
     hs = lj.parse_scene(scene_path("cbox"))

@@ -360,6 +360,35 @@ void twin_intersect_work(void *tv, int64_t n, const LjRay *rays, unsigned long l
     }
     work[0] += mem.n_nodes; work[1] += mem.n_prims;
 }
+// sample_cdf_guided against the full bisection on every environment-map table of the scene: random u, and the values around every
+// bin edge (b / n and its float neighbours) where a guide that is one entry short would show.  Returns the number of disagreements.
+long long twin_cdf_guide_mismatches(void *tv, int n_random) {
+    const DScene &sc = ((Twin *)tv)->view;
+    long long bad = 0, checked = 0;
+    uint64_t st = 0x1234567ull;
+    auto rnd = [&]() { st = st * 6364136223846793005ULL + 1442695040888963407ULL; return (float)((st >> 40) * (1.0 / 16777216.0)); };
+    auto check = [&](const float *cdf, const float *guide, int n, float u) {
+        if (!(u >= 0.0f && u < 1.0f)) return;
+        checked++;
+        const int want = sample_cdf(cdf, n, u);
+        if (want != sample_cdf_guided(cdf, guide, n, u)) bad++;
+        float c0 = -1.0f, c1 = -1.0f;
+        if (want != sample_cdf_guided(cdf, guide, n, u, c0, c1) || c0 != cdf[want] || c1 != cdf[want + 1]) bad++;
+    };
+    auto table = [&](const float *cdf, const float *guide, int n) {
+        for (int i = 0; i < n_random; i++) check(cdf, guide, n, rnd());
+        for (int b = 0; b <= n; b++) { const float e = (float)b / (float)n; check(cdf, guide, n, e); check(cdf, guide, n, nextafterf(e, 0.0f)); check(cdf, guide, n, nextafterf(e, 2.0f)); }
+        for (int i = 0; i <= n; i++) { check(cdf, guide, n, cdf[i]); check(cdf, guide, n, nextafterf(cdf[i], 0.0f)); check(cdf, guide, n, nextafterf(cdf[i], 2.0f)); }
+    };
+    for (int li = 0; li < sc.n_lights; li++) {
+        const DLight &L = sc.lights[li];
+        if (L.kind == 0) continue;
+        table(sc.env_tables + L.env_cdf_marg, sc.env_tables + L.env_guide_marg, L.env_h);
+        for (int y = 0; y < L.env_h; y += (L.env_h > 64 ? L.env_h / 64 : 1))
+            table(sc.env_tables + L.env_cdf_rows + (int64_t)y * (L.env_w + 1), sc.env_tables + L.env_guide_rows + (int64_t)y * L.env_w, L.env_w);
+    }
+    return checked > 0 ? bad : -1;
+}
 void twin_bvh8_info(void *tv, long long *out) {   // nodes, depth, filled slots, leaf slots
     Twin *t = (Twin *)tv;
     out[0] = (long long)t->flat.nodes8.size(); out[1] = t->flat.bvh8_depth; out[2] = out[3] = 0;
