@@ -129,6 +129,7 @@ struct DVolume {
     float p_min[3], p_max[3], max_data[3];
     float scale;
     int64_t offset;                  // of the first voxel, in floats
+    int32_t mono, _pad;              // 1: the grid's three channels are equal everywhere and ONE float per voxel is stored (a third of the gathers)
 };
 struct DMedium {
     int32_t kind, phase_kind;        // 0 homogeneous / 1 heterogeneous; 0 isotropic / 1 Henyey-Greenstein

@@ -39,11 +39,17 @@ LJ_HD f3 volume_lookup(const DScene &sc, const DVolume &v, f3 p) {
     const int x1 = clampi(x0 + 1, 0, rx - 1), y1 = clampi(y0 + 1, 0, ry - 1), z1 = clampi(z0 + 1, 0, rz - 1);
     const float dx = pn.x - x0, dy = pn.y - y0, dz = pn.z - z0;
     const float *base = sc.volume_data + v.offset;
+    const float w000 = (1 - dx) * (1 - dy) * (1 - dz), w100 = dx * (1 - dy) * (1 - dz), w010 = (1 - dx) * dy * (1 - dz), w110 = dx * dy * (1 - dz),
+                w001 = (1 - dx) * (1 - dy) * dz, w101 = dx * (1 - dy) * dz, w011 = (1 - dx) * dy * dz, w111 = dx * dy * dz;
+    if (v.mono) {   // one float per voxel: the same sum, once (each channel of the three-float form computes exactly this)
+        auto a1 = [&](int x, int y, int z) { return base[(size_t)(z * ry + y) * rx + x]; };
+        const float r = (a1(x0, y0, z0) * w000 + a1(x1, y0, z0) * w100 + a1(x0, y1, z0) * w010 + a1(x1, y1, z0) * w110 +
+                         a1(x0, y0, z1) * w001 + a1(x1, y0, z1) * w101 + a1(x0, y1, z1) * w011 + a1(x1, y1, z1) * w111) * v.scale;
+        return mk3(r, r, r);
+    }
     auto at = [&](int x, int y, int z) { return ld3(base + 3 * ((size_t)(z * ry + y) * rx + x)); };
-    return (at(x0, y0, z0) * ((1 - dx) * (1 - dy) * (1 - dz)) + at(x1, y0, z0) * (dx * (1 - dy) * (1 - dz)) +
-            at(x0, y1, z0) * ((1 - dx) * dy * (1 - dz)) + at(x1, y1, z0) * (dx * dy * (1 - dz)) +
-            at(x0, y0, z1) * ((1 - dx) * (1 - dy) * dz) + at(x1, y0, z1) * (dx * (1 - dy) * dz) +
-            at(x0, y1, z1) * ((1 - dx) * dy * dz) + at(x1, y1, z1) * (dx * dy * dz)) * v.scale;
+    return (at(x0, y0, z0) * w000 + at(x1, y0, z0) * w100 + at(x0, y1, z0) * w010 + at(x1, y1, z0) * w110 +
+            at(x0, y0, z1) * w001 + at(x1, y0, z1) * w101 + at(x0, y1, z1) * w011 + at(x1, y1, z1) * w111) * v.scale;
 }
 // intersect(Volume, ray) (volume.h:118-144)
 LJ_HD bool volume_intersect(const DVolume &v, f3 org, f3 dir, float tfar) {
@@ -258,133 +264,169 @@ LJ_HD f3 vol_path_sample_2(const DScene &sc, Tracer &tr, int x, int y, VolRng &r
 
 // vol_path_tracing (vol_path_tracing.h:503-869); see oracle/lj_oracle.cpp for the list of reference quirks kept.  Versions 3, 4 and 5 of
 // the reference return this function's result in their first statement (vol_path_tracing.h:880, 1052, 1297).
+// Cut at the top of its bounce loop: vol_path_begin sets up a camera sample, vol_path_step runs ONE iteration of the loop at
+// vol_path_tracing.h:524 and says whether there is another.  k_volpath keeps a path per lane and gives a lane whose path has ended the
+// next camera sample (regeneration), so a wave's lanes stay busy whatever their paths' lengths; vol_path_sample below is the two
+// chained, operation for operation what it was as one function.
+struct VolPath {
+    VolRng rng;
+    f3 org, dir; float spread;          // RayDifferential{0, 0}: only `spread` ever changes (ray.h:45-66 with radius 0)
+    int current_medium;
+    f3 throughput, radiance;
+    int bounces;
+    float dir_pdf; f3 nee_p_cache, multi_trans_pdf;
+    float eta_scale;
+    uint32_t bounce_iterations;         // (statistics: iterations that reached the scattering / shading part)
+    int guard;                          // Russian roulette ends a path with probability >= 5 % per iteration past rr_depth; the cap bounds rr_depth = huge
+};
+// returns false when the sample is already finished (`result`): versions 1 and 2 are single-shot estimators
 template <class Tracer>
-LJ_HD f3 vol_path_sample(const DScene &sc, Tracer &tr, int x, int y, uint64_t stream, uint64_t seed, uint32_t &bounces_out) {
-    VolRng rng; rng.inc = pcg32_inc(stream); rng.state = pcg32_init(stream, seed);
-    bounces_out = 0;
-    if (sc.vol_path_version == 1) return vol_path_sample_1(sc, tr, x, y, rng);
-    if (sc.vol_path_version == 2) return vol_path_sample_2(sc, tr, x, y, rng);
-    const float jy = vrnd(rng), jx = vrnd(rng);
-    f3 org = ld3(sc.cam.org), dir = camera_primary_dir(sc.cam, x, y, jx, jy);
-    float spread = 0.0f;   // RayDifferential{0, 0}: only `spread` ever changes (ray.h:45-66 with radius 0)
-    int current_medium = sc.cam_medium;
-    f3 throughput = mk3(1, 1, 1), radiance = mk3(0, 0, 0);
-    int bounces = 0;
-    float dir_pdf = 0.0f; f3 nee_p_cache = mk3(0, 0, 0);
-    f3 multi_trans_pdf = mk3(1, 1, 1);
-    float eta_scale = 1.0f;
-    bounces_out = 0;
-    // (Russian roulette ends a path with probability >= 5 % per iteration past rr_depth; the cap bounds rr_depth = huge)
-    for (int guard = 0; guard < 65536; guard++) {
-        bool scatter = false;
-        float t, hu, hv; int gprim;
-        const bool hit = tr.closest(org, dir, sc.eps, INFINITY, t, hu, hv, gprim);
-        DVertex vertex;
-        float t_hit = INFINITY;
-        if (hit) { vertex = build_vertex(sc, org, dir, t, hu, hv, gprim, spread); t_hit = length(vertex.position - org); }
-        f3 transmittance = mk3(1, 1, 1), trans_dir_pdf = mk3(1, 1, 1), trans_nee_pdf = mk3(1, 1, 1);
-        if (current_medium != -1) {
-            const DMedium &med = sc.media[current_medium];
-            const f3 majorant = get_majorant(med, org, dir, INFINITY);
-            const float u = vrnd(rng);
-            const int channel = (int)(u * 3.0f) < 0 ? 0 : ((int)(u * 3.0f) > 2 ? 2 : (int)(u * 3.0f));
-            float accum_t = 0.0f; int iteration = 0;
-            for (;;) {
-                if (vget3(majorant, channel) <= 0.0f) break;
-                if (iteration >= sc.max_null_collisions) break;
-                const float tt = -logf(1.0f - vrnd(rng)) / vget3(majorant, channel);
-                const float dt = t_hit - accum_t;
-                accum_t = fminf(accum_t + tt, t_hit);
-                if (tt < dt) {
-                    const f3 p = org + dir * accum_t;
-                    f3 ss, sa; get_sigmas(sc, med, p, ss, sa);
-                    const f3 real_prob = vdiv3(ss + sa, majorant), one_minus = mk3(1, 1, 1) - real_prob;
-                    const f3 e = vexp3_scaled(-(majorant * tt));
-                    const float mx = max3(majorant);
-                    if (vrnd(rng) < vget3(real_prob, channel)) {
-                        scatter = true;
-                        transmittance = transmittance * (e / mx);
-                        trans_dir_pdf = trans_dir_pdf * (e * majorant * real_prob / mx);
-                        org = p;
-                        break;
-                    }
-                    transmittance = transmittance * (e * (majorant * one_minus) / mx);
-                    trans_dir_pdf = trans_dir_pdf * (e * majorant * one_minus / mx);
-                    trans_nee_pdf = trans_nee_pdf * (e * majorant / mx);
-                } else {
-                    const f3 e = vexp3_scaled(-(majorant * dt));
-                    transmittance = transmittance * e; trans_dir_pdf = trans_dir_pdf * e; trans_nee_pdf = trans_nee_pdf * e;
-                    org = vertex.position;
+LJ_HD bool vol_path_begin(const DScene &sc, Tracer &tr, int x, int y, uint64_t stream, uint64_t seed, VolPath &P, f3 &result) {
+    P.rng.inc = pcg32_inc(stream); P.rng.state = pcg32_init(stream, seed);
+    P.bounce_iterations = 0; P.guard = 0;
+    if (sc.vol_path_version == 1) { result = vol_path_sample_1(sc, tr, x, y, P.rng); return false; }
+    if (sc.vol_path_version == 2) { result = vol_path_sample_2(sc, tr, x, y, P.rng); return false; }
+    const float jy = vrnd(P.rng), jx = vrnd(P.rng);
+    P.org = ld3(sc.cam.org); P.dir = camera_primary_dir(sc.cam, x, y, jx, jy);
+    P.spread = 0.0f;
+    P.current_medium = sc.cam_medium;
+    P.throughput = mk3(1, 1, 1); P.radiance = mk3(0, 0, 0);
+    P.bounces = 0;
+    P.dir_pdf = 0.0f; P.nee_p_cache = mk3(0, 0, 0);
+    P.multi_trans_pdf = mk3(1, 1, 1);
+    P.eta_scale = 1.0f;
+    return true;
+}
+// one iteration of the loop; false: the path has ended with `result`
+template <class Tracer>
+LJ_HD bool vol_path_step(const DScene &sc, Tracer &tr, VolPath &P, f3 &result) {
+    VolRng &rng = P.rng;
+    f3 &org = P.org, &dir = P.dir; float &spread = P.spread;
+    int &current_medium = P.current_medium;
+    f3 &throughput = P.throughput, &radiance = P.radiance;
+    int &bounces = P.bounces;
+    float &dir_pdf = P.dir_pdf; f3 &nee_p_cache = P.nee_p_cache, &multi_trans_pdf = P.multi_trans_pdf;
+    float &eta_scale = P.eta_scale;
+    uint32_t &bounces_out = P.bounce_iterations;
+    if (P.guard >= 65536) { result = radiance; return false; }
+    P.guard++;
+    bool scatter = false;
+    float t, hu, hv; int gprim;
+    const bool hit = tr.closest(org, dir, sc.eps, INFINITY, t, hu, hv, gprim);
+    DVertex vertex;
+    float t_hit = INFINITY;
+    if (hit) { vertex = build_vertex(sc, org, dir, t, hu, hv, gprim, spread); t_hit = length(vertex.position - org); }
+    f3 transmittance = mk3(1, 1, 1), trans_dir_pdf = mk3(1, 1, 1), trans_nee_pdf = mk3(1, 1, 1);
+    if (current_medium != -1) {
+        const DMedium &med = sc.media[current_medium];
+        const f3 majorant = get_majorant(med, org, dir, INFINITY);
+        const float u = vrnd(rng);
+        const int channel = (int)(u * 3.0f) < 0 ? 0 : ((int)(u * 3.0f) > 2 ? 2 : (int)(u * 3.0f));
+        float accum_t = 0.0f; int iteration = 0;
+        for (;;) {
+            if (vget3(majorant, channel) <= 0.0f) break;
+            if (iteration >= sc.max_null_collisions) break;
+            const float tt = -logf(1.0f - vrnd(rng)) / vget3(majorant, channel);
+            const float dt = t_hit - accum_t;
+            accum_t = fminf(accum_t + tt, t_hit);
+            if (tt < dt) {
+                const f3 p = org + dir * accum_t;
+                f3 ss, sa; get_sigmas(sc, med, p, ss, sa);
+                const f3 real_prob = vdiv3(ss + sa, majorant), one_minus = mk3(1, 1, 1) - real_prob;
+                const f3 e = vexp3_scaled(-(majorant * tt));
+                const float mx = max3(majorant);
+                if (vrnd(rng) < vget3(real_prob, channel)) {
+                    scatter = true;
+                    transmittance = transmittance * (e / mx);
+                    trans_dir_pdf = trans_dir_pdf * (e * majorant * real_prob / mx);
+                    org = p;
                     break;
                 }
-                iteration++;
+                transmittance = transmittance * (e * (majorant * one_minus) / mx);
+                trans_dir_pdf = trans_dir_pdf * (e * majorant * one_minus / mx);
+                trans_nee_pdf = trans_nee_pdf * (e * majorant / mx);
+            } else {
+                const f3 e = vexp3_scaled(-(majorant * dt));
+                transmittance = transmittance * e; trans_dir_pdf = trans_dir_pdf * e; trans_nee_pdf = trans_nee_pdf * e;
+                org = vertex.position;
+                break;
             }
-            multi_trans_pdf = multi_trans_pdf * trans_dir_pdf;
-        } else {
-            if (hit) org = vertex.position;
-            else return mk3(0, 0, 0);
+            iteration++;
         }
-        throughput = throughput * (transmittance / vavg3(trans_dir_pdf));
-        if (!scatter && hit && vertex.light_id >= 0) {
-            const DLight &EL = sc.lights[vertex.light_id];
-            const f3 Le = light_emission(sc, EL, -dir, vertex.gn);
-            if (bounces == 0) return radiance + throughput * Le;
-            const f3 pdf_nee = trans_nee_pdf * (EL.pmf * pdf_point_on_light(sc, EL, vertex.position, vertex.gn, nee_p_cache));
-            const f3 dv = nee_p_cache - vertex.position;
-            const float jacobian = fmaxf(-dot(-dir, vertex.gn), 0.0f) / dot(dv, dv);
-            const f3 pdf_phase = multi_trans_pdf * (dir_pdf * jacobian);
-            const f3 p2 = pdf_phase * pdf_phase, n2 = pdf_nee * pdf_nee;
-            radiance = radiance + throughput * Le * vdiv3(p2, p2 + n2);
-        }
-        if (!scatter && hit && vertex.material_id == -1) {
-            current_medium = update_medium(sc, vertex, dir, current_medium);
-            org = vertex.position;
-            bounces++;
-            continue;
-        }
-        if (bounces >= sc.max_depth - 1 && sc.max_depth != -1) break;
-        bounces_out++;
-        if (scatter && current_medium != -1) {
-            const DMedium &med = sc.media[current_medium];
-            f3 sigma_s, sigma_a; get_sigmas(sc, med, org, sigma_s, sigma_a);
-            const f3 nee = vol_nee(sc, tr, rng, org, current_medium, bounces, -dir, false, vertex);
-            radiance = radiance + throughput * sigma_s * nee;
-            if (max3(nee) > 0.0f) nee_p_cache = org;
-            const float r0 = vrnd(rng), r1 = vrnd(rng);
-            const f3 next_dir = phase_sample(med, -dir, r0, r1);
-            const float phase_pdf = phase_eval(med, -dir, next_dir);
-            throughput = throughput * sigma_s * (phase_pdf / phase_pdf);
-            dir = next_dir;
-            dir_pdf = phase_pdf;
-            multi_trans_pdf = mk3(1, 1, 1);
-        } else if (hit) {
-            const f3 nee = vol_nee(sc, tr, rng, org, current_medium, bounces, -dir, true, vertex);
-            radiance = radiance + throughput * nee;
-            if (max3(nee) > 0.0f) nee_p_cache = org;
-            const DMaterial &mat = sc.materials[vertex.material_id];
-            const f3 dir_view = -dir;
-            const float b0 = vrnd(rng), b1 = vrnd(rng), bw = vrnd(rng);
-            const BsdfSample bs = bsdf_sample(sc, mat, dir_view, vertex, b0, b1, bw);
-            if (!bs.valid) break;
-            dir = bs.dir_out;
-            if (bs.eta == 0.0f) spread = fmaxf(spread * (1.0f - bs.roughness) + 0.2f * bs.roughness, 0.0f);
-            else {
-                spread = fmaxf((spread / bs.eta) * (1.0f - bs.roughness) + 0.2f * bs.roughness, 0.0f);
-                eta_scale /= (bs.eta * bs.eta);
-                current_medium = update_medium(sc, vertex, dir, current_medium);
-            }
-            f3 f; float pdf_bsdf;
-            bsdf_eval_pdf(sc, mat, dir_view, bs.dir_out, vertex, f, pdf_bsdf);
-            throughput = throughput * (f / pdf_bsdf);
-        }
-        if (bounces >= sc.rr_depth) {
-            const float rr_prob = fminf(max3(throughput * (1.0f / eta_scale)), 0.95f);
-            if (vrnd(rng) > rr_prob) break;
-            throughput = throughput / rr_prob;
-        }
-        bounces++;
+        multi_trans_pdf = multi_trans_pdf * trans_dir_pdf;
+    } else {
+        if (hit) org = vertex.position;
+        else { result = mk3(0, 0, 0); return false; }
     }
-    return radiance;
+    throughput = throughput * (transmittance / vavg3(trans_dir_pdf));
+    if (!scatter && hit && vertex.light_id >= 0) {
+        const DLight &EL = sc.lights[vertex.light_id];
+        const f3 Le = light_emission(sc, EL, -dir, vertex.gn);
+        if (bounces == 0) { result = radiance + throughput * Le; return false; }
+        const f3 pdf_nee = trans_nee_pdf * (EL.pmf * pdf_point_on_light(sc, EL, vertex.position, vertex.gn, nee_p_cache));
+        const f3 dv = nee_p_cache - vertex.position;
+        const float jacobian = fmaxf(-dot(-dir, vertex.gn), 0.0f) / dot(dv, dv);
+        const f3 pdf_phase = multi_trans_pdf * (dir_pdf * jacobian);
+        const f3 p2 = pdf_phase * pdf_phase, n2 = pdf_nee * pdf_nee;
+        radiance = radiance + throughput * Le * vdiv3(p2, p2 + n2);
+    }
+    if (!scatter && hit && vertex.material_id == -1) {
+        current_medium = update_medium(sc, vertex, dir, current_medium);
+        org = vertex.position;
+        bounces++;
+        return true;
+    }
+    if (bounces >= sc.max_depth - 1 && sc.max_depth != -1) { result = radiance; return false; }
+    bounces_out++;
+    if (scatter && current_medium != -1) {
+        const DMedium &med = sc.media[current_medium];
+        f3 sigma_s, sigma_a; get_sigmas(sc, med, org, sigma_s, sigma_a);
+        const f3 nee = vol_nee(sc, tr, rng, org, current_medium, bounces, -dir, false, vertex);
+        radiance = radiance + throughput * sigma_s * nee;
+        if (max3(nee) > 0.0f) nee_p_cache = org;
+        const float r0 = vrnd(rng), r1 = vrnd(rng);
+        const f3 next_dir = phase_sample(med, -dir, r0, r1);
+        const float phase_pdf = phase_eval(med, -dir, next_dir);
+        throughput = throughput * sigma_s * (phase_pdf / phase_pdf);
+        dir = next_dir;
+        dir_pdf = phase_pdf;
+        multi_trans_pdf = mk3(1, 1, 1);
+    } else if (hit) {
+        const f3 nee = vol_nee(sc, tr, rng, org, current_medium, bounces, -dir, true, vertex);
+        radiance = radiance + throughput * nee;
+        if (max3(nee) > 0.0f) nee_p_cache = org;
+        const DMaterial &mat = sc.materials[vertex.material_id];
+        const f3 dir_view = -dir;
+        const float b0 = vrnd(rng), b1 = vrnd(rng), bw = vrnd(rng);
+        const BsdfSample bs = bsdf_sample(sc, mat, dir_view, vertex, b0, b1, bw);
+        if (!bs.valid) { result = radiance; return false; }
+        dir = bs.dir_out;
+        if (bs.eta == 0.0f) spread = fmaxf(spread * (1.0f - bs.roughness) + 0.2f * bs.roughness, 0.0f);
+        else {
+            spread = fmaxf((spread / bs.eta) * (1.0f - bs.roughness) + 0.2f * bs.roughness, 0.0f);
+            eta_scale /= (bs.eta * bs.eta);
+            current_medium = update_medium(sc, vertex, dir, current_medium);
+        }
+        f3 f; float pdf_bsdf;
+        bsdf_eval_pdf(sc, mat, dir_view, bs.dir_out, vertex, f, pdf_bsdf);
+        throughput = throughput * (f / pdf_bsdf);
+    }
+    if (bounces >= sc.rr_depth) {
+        const float rr_prob = fminf(max3(throughput * (1.0f / eta_scale)), 0.95f);
+        if (vrnd(rng) > rr_prob) { result = radiance; return false; }
+        throughput = throughput / rr_prob;
+    }
+    bounces++;
+    return true;
+}
+template <class Tracer>
+LJ_HD f3 vol_path_sample(const DScene &sc, Tracer &tr, int x, int y, uint64_t stream, uint64_t seed, uint32_t &bounces_out) {
+    VolPath P; f3 result = mk3(0, 0, 0);
+    bounces_out = 0;
+    if (!vol_path_begin(sc, tr, x, y, stream, seed, P, result)) return result;
+    while (vol_path_step(sc, tr, P, result)) {}
+    bounces_out = P.bounce_iterations;
+    return result;
 }
 
 } // namespace ljd

@@ -18,6 +18,7 @@
 //   k_trace_rays             : batched intersect()/occluded() for the parity tests
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <algorithm>
 #include "dstage.h"
 #include "dvol.h"
 #include "dtrace.h"
@@ -755,32 +756,71 @@ struct DevTracer {
     }
 };
 
-__device__ __forceinline__ void volpath_body(const DScene &sc, const DPass &pass, uint32_t n_samples, unsigned long long *bounce_counter, int stack, int lds_nodes, int lds_prims, int *spill) {
+// Persistent waves with path regeneration (the structure of k_mega): every lane carries one path, bounce by bounce (dvol.h
+// vol_path_step); a lane whose path has ended takes the next camera sample of its wave's open range, and a wave whose range is used
+// up takes the next `grab` samples off one grid-wide counter — so the lanes of a wave stay busy whatever the lengths of their paths
+// (one whole path per lane left a wave waiting for its longest path).  A sample's value depends on its pcg32 stream only.
+// counters[0..1]: bounce iterations (64 bit); counters[2]: the sample counter (zeroed before the launch).
+__device__ __forceinline__ void volpath_body(const DScene &sc, const DPass &pass, uint32_t n_samples, uint32_t grab, uint32_t *counters, int stack, int lds_nodes, int lds_prims, int *spill) {
     const TreeView tv = stage_tree(sc, stack, lds_nodes, lds_prims, spill, gridDim.x * kBlock, blockIdx.x * kBlock + threadIdx.x);
     DevTracer tr{tv};
+    uint32_t *sample_counter = counters + 2;
+    const uint32_t lane = threadIdx.x & 63u;
     uint32_t bounces = 0;
-    for (uint32_t s = blockIdx.x * kBlock + threadIdx.x; s < n_samples; s += gridDim.x * kBlock) {
-        const uint32_t p = s / pass.spp, k = s - p * pass.spp;
-        const uint32_t pixel = pass.pixel_list[p];
-        uint32_t nb = 0;
-        f3 rad = vol_path_sample(sc, tr, (int)(pixel % (uint32_t)sc.cam.width), (int)(pixel / (uint32_t)sc.cam.width), (uint64_t)pixel * pass.spp + k, pass.seed, nb);
+    bool live = false, exhausted = false;
+    uint32_t w_next = 0, w_end = 0;   // the wave's open range of camera samples (wave-uniform)
+    uint32_t sample = 0;
+    VolPath P;
+    auto finish = [&](uint32_t s, f3 rad, uint32_t nb) {
         if (!(isfinite(rad.x) && isfinite(rad.y) && isfinite(rad.z))) rad = mk3(0, 0, 0);   // render.cpp:138-141: a non-finite sample is left out
         float *o = pass.sample_rgb + 3ull * s;
         o[0] = rad.x; o[1] = rad.y; o[2] = rad.z;
         bounces += nb;
+    };
+    for (;;) {
+        const unsigned long long dead = __ballot(!live);
+        if (dead != 0ull && !exhausted) {
+            if (w_next == w_end) {
+                uint32_t b = 0;
+                if (lane == 0u) b = atomicAdd(sample_counter, grab);
+                b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+                if (b >= n_samples) exhausted = true;
+                else { w_next = b; w_end = (n_samples - b < grab) ? n_samples : b + grab; }
+            }
+            if (!exhausted) {
+                const uint32_t left = w_end - w_next, n_dead = (uint32_t)__popcll(dead);
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(dead >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dead, 0u));
+                if (!live && rank < left) {
+                    sample = w_next + rank;
+                    const uint32_t p = sample / pass.spp, k = sample - p * pass.spp;
+                    const uint32_t pixel = pass.pixel_list[p];
+                    f3 rad;
+                    live = vol_path_begin(sc, tr, (int)(pixel % (uint32_t)sc.cam.width), (int)(pixel / (uint32_t)sc.cam.width), (uint64_t)pixel * pass.spp + k, pass.seed, P, rad);
+                    if (!live) finish(sample, rad, 0u);   // (the single-shot estimators of version 1 and 2)
+                }
+                w_next += n_dead < left ? n_dead : left;
+            }
+        }
+        if (__ballot(live) == 0ull) { if (exhausted) break; else continue; }
+        if (live) {
+            f3 rad;
+            if (!vol_path_step(sc, tr, P, rad)) { finish(sample, rad, P.bounce_iterations); live = false; }
+        }
     }
     const uint32_t wb = wave_sum(bounces);
-    if ((threadIdx.x & 63) == 0 && wb) atomicAdd(bounce_counter, (unsigned long long)wb);
+    if (lane == 0u && wb) atomicAdd((unsigned long long *)counters, (unsigned long long)wb);
 }
-// Two builds of the same body.  Unconstrained it takes 252 VGPRs (two waves per SIMD); built for three waves (168, some spilled) the
-// scenes with homogeneous media run 7-20 % faster at their shipped sample counts (volpath_test4 / 5 / 6, vol_cbox_teapot;
-// volpath_test2 +4 %), but a heterogeneous medium — whose tracker keeps the grid-lookup state live through long null-collision loops —
-// 30 % slower (hetvol 64 spp: 183 -> 238 ms).  The launcher picks by whether the scene holds a heterogeneous medium.
-__global__ void __launch_bounds__(kBlock) k_volpath(DScene sc, DPass pass, uint32_t n_samples, unsigned long long *bounce_counter, int stack, int lds_nodes, int lds_prims, int *spill) {
-    volpath_body(sc, pass, n_samples, bounce_counter, stack, lds_nodes, lds_prims, spill);
+// Two builds of the same body.  Unconstrained it takes ~250 VGPRs (two waves per SIMD); built for three waves (168, some spilled) the
+// scenes with homogeneous media run faster, but a heterogeneous medium — whose tracker keeps the grid-lookup state live through long
+// null-collision loops — slower.  The launcher picks by whether the scene holds a heterogeneous medium.
+__global__ void __launch_bounds__(kBlock) k_volpath(DScene sc, DPass pass, uint32_t n_samples, uint32_t grab, uint32_t *counters, int stack, int lds_nodes, int lds_prims, int *spill) {
+    volpath_body(sc, pass, n_samples, grab, counters, stack, lds_nodes, lds_prims, spill);
 }
-__global__ void __launch_bounds__(kBlock, 3) k_volpath3(DScene sc, DPass pass, uint32_t n_samples, unsigned long long *bounce_counter, int stack, int lds_nodes, int lds_prims, int *spill) {
-    volpath_body(sc, pass, n_samples, bounce_counter, stack, lds_nodes, lds_prims, spill);
+__global__ void __launch_bounds__(kBlock, 3) k_volpath3(DScene sc, DPass pass, uint32_t n_samples, uint32_t grab, uint32_t *counters, int stack, int lds_nodes, int lds_prims, int *spill) {
+    volpath_body(sc, pass, n_samples, grab, counters, stack, lds_nodes, lds_prims, spill);
+}
+__global__ void __launch_bounds__(kBlock, 4) k_volpath4(DScene sc, DPass pass, uint32_t n_samples, uint32_t grab, uint32_t *counters, int stack, int lds_nodes, int lds_prims, int *spill) {
+    volpath_body(sc, pass, n_samples, grab, counters, stack, lds_nodes, lds_prims, spill);
 }
 
 // ---------------------------------------------------------------- launchers (called from api_device.hip)
@@ -927,13 +967,23 @@ void launch_resolve(const DPass &pass, uint32_t n_pixels, float *rgb, hipStream_
 void launch_aux(const DScene &sc, const uint32_t *pixel_list, uint32_t n_pixels, int integrator, float *rgb, const ExtendConfig &cfg, int *spill, int grid, hipStream_t s) {
     if (n_pixels) hipLaunchKernelGGL(k_aux, dim3(grid), dim3(kBlock), cfg.smem, s, sc, pixel_list, n_pixels, integrator, rgb, cfg.stack, cfg.lds_nodes, cfg.lds_prims, spill);
 }
-void launch_volpath(const DScene &sc, const DPass &pass, uint32_t n_samples, unsigned long long *bounce_counter, const ExtendConfig &cfg, int *spill, int grid, hipStream_t s) {
+void launch_volpath(const DScene &sc, const DPass &pass, uint32_t n_samples, uint32_t *counters, const ExtendConfig &cfg, int *spill, int grid, hipStream_t s) {
     if (!n_samples) return;
-    bool hetero = false;
-    if (const char *e = getenv("LJ_TUNE_VOLPATH_OCC")) hetero = atoi(e) == 2;
-    else hetero = sc.has_heterogeneous_medium != 0;
-    if (hetero) hipLaunchKernelGGL(k_volpath, dim3(grid), dim3(kBlock), cfg.smem, s, sc, pass, n_samples, bounce_counter, cfg.stack, cfg.lds_nodes, cfg.lds_prims, spill);
-    else hipLaunchKernelGGL(k_volpath3, dim3(grid), dim3(kBlock), cfg.smem, s, sc, pass, n_samples, bounce_counter, cfg.stack, cfg.lds_nodes, cfg.lds_prims, spill);
+    int occ = sc.has_heterogeneous_medium != 0 ? 2 : 3;
+    if (const char *e = getenv("LJ_TUNE_VOLPATH_OCC")) occ = atoi(e);
+    // camera samples a wave takes off the counter at a time: every wave draws ~16 times, at least four samples per lane and at most 128 —
+    // a single address takes ~90 atomics per microsecond, which short paths (an absorbing medium: one step per sample) would otherwise feel
+    const uint64_t waves = (uint64_t)grid * (kBlock / 64);
+    uint32_t grab = (uint32_t)std::min<uint64_t>(8192, std::max<uint64_t>(256, (n_samples / (waves * 16)) & ~(uint64_t)63));
+    if (const char *e = getenv("LJ_TUNE_VOLPATH_GRAB")) grab = (uint32_t)(atoi(e) < 64 ? 64 : atoi(e)) & ~63u;
+    auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), cfg.smem, s, sc, pass, n_samples, grab, counters, cfg.stack, cfg.lds_nodes, cfg.lds_prims, spill); };
+    if (occ <= 2) launch(k_volpath); else if (occ == 3) launch(k_volpath3); else launch(k_volpath4);
+}
+int volpath_blocks_per_cu(const DScene &sc) {   // workgroups that stay resident per CU: the persistent grid is n_cus x this
+    if (const char *e = getenv("LJ_TUNE_VOLPATH_BLOCKS_PER_CU")) return atoi(e) > 0 ? atoi(e) : 1;
+    int occ = sc.has_heterogeneous_medium != 0 ? 2 : 3;
+    if (const char *e = getenv("LJ_TUNE_VOLPATH_OCC")) occ = atoi(e);
+    return occ < 2 ? 2 : (occ > 4 ? 4 : occ);
 }
 void launch_trace_rays(const DScene &sc, const void *rays, long long n, void *hits, unsigned char *occ, const ExtendConfig &cfg, int *spill, int grid, hipStream_t s) {
     if (cfg.wide) { launch_trace_rays8(sc, rays, n, hits, occ, cfg, spill, grid, s); return; }

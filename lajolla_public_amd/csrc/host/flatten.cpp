@@ -151,9 +151,14 @@ FlatScene flatten_scene(const LjSceneDesc &d) {
             for (int k = 0; k < 3; k++) { r.res[k] = v.resolution[k]; r.value[k] = (float)v.value[k]; r.p_min[k] = (float)v.p_min[k]; r.p_max[k] = (float)v.p_max[k]; r.max_data[k] = (float)v.max_data[k]; }
             if (m.kind == LJ_MEDIUM_HETEROGENEOUS && v.kind == LJ_VOLUME_GRID) {
                 if (!v.data || v.resolution[0] <= 0 || v.resolution[1] <= 0 || v.resolution[2] <= 0) throw LjError(LJ_ERR_INVALID_ARG, "grid volume without voxels");
-                const size_t n = (size_t)v.resolution[0] * v.resolution[1] * v.resolution[2] * 3;
+                const size_t nvox = (size_t)v.resolution[0] * v.resolution[1] * v.resolution[2], n = nvox * 3;
                 r.offset = (int64_t)F.volume_data.size();
-                F.volume_data.insert(F.volume_data.end(), v.data, v.data + n);
+                // a grid whose three channels agree in every voxel (a one-channel .vol file, volume.cpp) is stored as one float per voxel
+                bool mono = true;
+                for (size_t i = 0; i < nvox && mono; i++) mono = memcmp(&v.data[3 * i], &v.data[3 * i + 1], 4) == 0 && memcmp(&v.data[3 * i], &v.data[3 * i + 2], 4) == 0;
+                r.mono = mono ? 1 : 0;
+                if (mono) { F.volume_data.reserve(F.volume_data.size() + nvox); for (size_t i = 0; i < nvox; i++) F.volume_data.push_back(v.data[3 * i]); }
+                else F.volume_data.insert(F.volume_data.end(), v.data, v.data + n);
             }
             return r;
         };

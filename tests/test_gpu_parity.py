@@ -71,7 +71,10 @@ def test_edge_cases_of_the_ray_queries(scene):
 
 CROPS = {"cbox": [(200, 200, 232, 232), (0, 0, 48, 32)], "veach_mi": [(300, 200, 348, 232), (100, 380, 132, 412)],
          "disney_bsdf": [(300, 200, 332, 232), (150, 330, 190, 360)], "sponza": [(300, 300, 332, 332), (420, 100, 452, 132)]}
-BARS = {"sponza": dict(median=1e-4, diverged=0.15, mean=5e-3, l2=3e-2, k=2e-2, img_mean=2e-3)}
+# sponza: float shading moves a texel coordinate of its 1000-texel tiled textures by ~1e-4 texel against the oracle's double, and every
+# later vertex inherits the difference (measured on the host build of the device code: median 5e-5, 8 % of samples beyond 1e-3 at full
+# depth).  The allowance is therefore graded by depth (test_sponza_parity_by_depth): paths of one bounce are held to 2 %.
+BARS = {"sponza": dict(median=1e-4, diverged=0.10, mean=2e-3, l2=3e-2, k=2e-2, img_mean=2e-3)}
 DEFAULT_BARS = dict(median=2e-6, diverged=0.02, mean=2e-4, l2=1e-2, k=5e-3, img_mean=2e-4)
 
 
@@ -95,6 +98,23 @@ def test_per_sample_parity(scene):
         assert abs(d.sum()) <= 4.0 * np.sqrt((d * d).sum()) + 1e-7 * np.abs(ps).sum() + 1e-6
         k_gpu = sc.stats().bounce_iterations / sc.stats().samples
         assert abs(k_gpu / (st.bounces / st.samples) - 1) < bars["k"]
+
+
+def test_sponza_parity_by_depth(ctx):
+    """The widest door of this suite, narrowed: with max_depth 2 (camera ray, one next-event estimate, one bounce to an emitter) the device
+    and the oracle shade the SAME first hit — bit-identical hit record, textures looked up at the same double uv — so a texture, light or
+    BSDF fault cannot hide behind the divergence of long float paths: at most 2 % of samples beyond 1e-3, means within 1e-4; max_depth 3: 5 %."""
+    hs = lj.parse_scene(scene_path("sponza"))
+    sc, o = lj.Scene(ctx, hs), Oracle(hs)
+    for max_depth, diverged, median, mean in ((2, 0.02, 5e-5, 1e-4), (3, 0.05, 1e-4, 3e-4)):
+        for crop in CROPS["sponza"]:
+            rc, _, ps, _ = o.render(spp=16, rng_mode=0, crop=crop, per_sample=True, max_depth=max_depth)
+            assert rc == 0
+            pg = lj.render_samples(sc, crop, spp=16, max_depth=max_depth)
+            rel = np.abs(pg - ps).max(axis=-1) / np.maximum(np.abs(ps).max(axis=-1), 1e-3)
+            assert np.median(rel) < median, (max_depth, crop, np.median(rel))
+            assert (rel > 1e-3).mean() < diverged, (max_depth, crop, (rel > 1e-3).mean())
+            assert abs(pg.mean() / ps.mean() - 1) < mean, (max_depth, crop)
 
 
 def test_image_l2_against_oracle(scene):
