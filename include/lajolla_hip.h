@@ -187,6 +187,8 @@ typedef struct lj_context lj_context;  /* one HIP device + stream + workspace; m
 typedef struct lj_scene lj_scene;      /* device-resident Scene: flattened BVH + tables; scene.cpp:3-53 analogue */
 
 int lj_context_create(int device_id, lj_context **out);
+/* Lifetime: scenes keep their context alive.  Destroying a context (or a device group, below) that still has scenes only marks it; the
+ * last lj_scene_destroy (lj_group_scene_destroy) releases it — any destruction order is safe, every handle is destroyed exactly once. */
 void lj_context_destroy(lj_context *ctx);
 
 /* Replaces Scene::Scene (scene.cpp:3-53): builds the BVH (instead of rtcCommitScene), the bounds sphere,

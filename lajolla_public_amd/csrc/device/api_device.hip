@@ -128,7 +128,7 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
         if (ctx->sample_rgb.bytes < pass_samples_max * 12) ctx->sample_rgb.alloc(pass_samples_max * 12);
         if (!ctx->chunk_counter.p) ctx->chunk_counter.alloc(128 * kMaxLanes);
         upload_pixel_list(ctx, plan, stream);
-        HIP_CHECK(hipMemsetAsync(ctx->chunk_counter.p, 0, 8, stream));
+        HIP_CHECK(hipMemsetAsync(ctx->chunk_counter.p, 0, 256, stream));
         HIP_CHECK(hipEventRecord(ctx->ev_begin, stream));
         for (uint64_t p0 = 0; p0 < n_pix; p0 += pix_per_pass) {
             const uint64_t np = std::min<uint64_t>(pix_per_pass, n_pix - p0);
@@ -155,6 +155,12 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
         unsigned long long nb = 0;
         HIP_CHECK(hipMemcpy(&nb, ctx->chunk_counter.p, 8, hipMemcpyDeviceToHost));
         st.render_ms = ms; st.bounce_iterations = nb;
+        if (getenv("LJ_VOLPATH_STATS")) {   // developer build only (-DLJ_VOLPATH_STATS=1): events and lane-events per part of the tracer
+            unsigned long long h[32];
+            HIP_CHECK(hipMemcpy(h, ctx->chunk_counter.p, sizeof(h), hipMemcpyDeviceToHost));
+            const char *names[8] = {"node iterations", "leaf steps", "closest calls", "tracking (bounce ray)", "tracking (shadow segment)", "shadow segments", "path steps", "-"};
+            for (int k = 0; k < 7; k++) fprintf(stderr, "[volpath stats] %-26s wave events %12llu  lanes active %5.1f %%  per sample %.2f\n", names[k], h[2 + 2 * k], h[2 + 2 * k] ? 100.0 * h[3 + 2 * k] / (64.0 * h[2 + 2 * k]) : 0.0, (double)h[3 + 2 * k] / (double)st.samples);
+        }
         return;
     }
     // ---- tiny scenes (flat leaf table, shading tables in LDS): the fused persistent kernel, one launch per pass (mega.hip)
@@ -446,6 +452,7 @@ int lj_context_create(int device_id, lj_context **out) {
 
 void lj_context_destroy(lj_context *ctx) {
     if (!ctx) return;
+    if (ctx->live_scenes > 0) { ctx->doomed = true; return; }   // released by the last lj_scene_destroy
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
     for (auto &ls : ctx->lane_streams) if (ls) { (void)hipStreamSynchronize(ls); (void)hipStreamDestroy(ls); }
@@ -512,15 +519,18 @@ int lj_scene_upload(lj_context *ctx, const LjSceneDesc *desc, lj_scene **out) {
             if (const char *e = getenv("LJ_TUNE_SHADE_VARIANT")) sc->scfg.variant = std::max(sc->scfg.variant, atoi(e));
             if (sc->scfg.smem == 0) sc->scfg.variant = ljd::kShadeVariantAll;   // tables too large to stage: one instantiation serves that case
         }
+        ctx->live_scenes++;
         *out = sc.release();
     });
 }
 
 void lj_scene_destroy(lj_scene *scene) {
     if (!scene) return;
-    (void)hipSetDevice(scene->ctx->device);
-    (void)hipStreamSynchronize(scene->ctx->stream);
+    lj_context *ctx = scene->ctx;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
     delete scene;
+    if (--ctx->live_scenes == 0 && ctx->doomed) lj_context_destroy(ctx);
 }
 
 int lj_render_device(lj_scene *scene, const LjRenderArgs *args, float *rgb_device, void *hip_stream) {

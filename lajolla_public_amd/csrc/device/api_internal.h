@@ -59,6 +59,9 @@ static constexpr uint32_t kMaxBlocks = 8192;
 static constexpr uint32_t kMaxLanes = 8;   // render lanes (streams) a context can run side by side
 struct lj_context {
     int device = 0;
+    // lifetime: a context outlives its scenes whatever order the caller destroys them in — lj_context_destroy on a context that still
+    // has scenes only marks it, and the last lj_scene_destroy releases it
+    int live_scenes = 0; bool doomed = false;
     hipStream_t stream = nullptr;
     hipStream_t lane_streams[kMaxLanes - 1] = {};   // further lanes of a render (run_render)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_caller = nullptr;

@@ -9,6 +9,7 @@
 // no BASELINE config uses it, so it is built for correctness, not for the roofline.
 //
 // Tracer provides:  bool closest(f3 org, f3 dir, float tnear, float tfar, float &t, float &u, float &v, int &gprim);
+//                   void tick(int slot);   (developer instrumentation of the device kernel: a no-op everywhere else)
 #pragma once
 #include "dshade.h"
 
@@ -129,6 +130,7 @@ LJ_HD f3 vol_nee(const DScene &sc, Tracer &tr, VolRng &rng, f3 p, int current_me
     // (every pass moves p at least eps along the ray, so the walk ends; the cap only bounds a degenerate scene)
     for (int segment = 0;; segment++) {
         if (segment >= 4096) return mk3(0, 0, 0);
+        tr.tick(5);
         const double dist_d = dist_to(p);
         const float dist_to_light = (float)dist_d;
         float t, hu, hv; int gprim;
@@ -145,6 +147,7 @@ LJ_HD f3 vol_nee(const DScene &sc, Tracer &tr, VolRng &rng, f3 p, int current_me
             for (;;) {
                 if (vget3(majorant, channel) <= 0.0f) break;
                 if (iteration >= sc.max_null_collisions) break;
+                tr.tick(4);
                 const float tt = -logf(1.0f - vrnd(rng)) / vget3(majorant, channel);
                 const float dt = next_t - accum_t;
                 accum_t = fminf(accum_t + tt, next_t);
@@ -326,6 +329,7 @@ LJ_HD bool vol_path_step(const DScene &sc, Tracer &tr, VolPath &P, f3 &result) {
         for (;;) {
             if (vget3(majorant, channel) <= 0.0f) break;
             if (iteration >= sc.max_null_collisions) break;
+            tr.tick(3);
             const float tt = -logf(1.0f - vrnd(rng)) / vget3(majorant, channel);
             const float dt = t_hit - accum_t;
             accum_t = fminf(accum_t + tt, t_hit);

@@ -53,6 +53,7 @@ struct lj_device_group {
     std::vector<lj_context *> ctx;
     std::vector<ncclComm_t> comm;   // one per device when RCCL is in use, else empty
     bool use_rccl = false;
+    int live_scenes = 0; bool doomed = false;   // (lifetime: as lj_context — the group is released by its last scene if it was destroyed first)
     std::vector<DevBuf *> frame;    // one full float frame per device, grown on demand
     DevBuf staging;                 // device 0: a peer's frame, for the RCCL-free sum
     ~lj_device_group() {
@@ -67,7 +68,7 @@ struct lj_group_scene {
     lj_device_group *group = nullptr;
     std::vector<lj_scene *> scene;
     LjStats stats{};
-    ~lj_group_scene() { for (lj_scene *s : scene) lj_scene_destroy(s); }
+    ~lj_group_scene() { for (lj_scene *s : scene) lj_scene_destroy(s); }   // (lj_group_scene_destroy does the group's bookkeeping)
 };
 
 extern "C" {
@@ -99,7 +100,11 @@ int lj_group_create(int n_devices, const int *device_ids, lj_device_group **out)
     });
 }
 
-void lj_group_destroy(lj_device_group *group) { delete group; }
+void lj_group_destroy(lj_device_group *group) {
+    if (!group) return;
+    if (group->live_scenes > 0) { group->doomed = true; return; }   // released by the last lj_group_scene_destroy
+    delete group;
+}
 int lj_group_size(const lj_device_group *group) { return group ? (int)group->ctx.size() : 0; }
 lj_context *lj_group_context(lj_device_group *group, int i) { return (group && i >= 0 && i < (int)group->ctx.size()) ? group->ctx[i] : nullptr; }
 int lj_group_uses_rccl(const lj_device_group *group) { return (group && group->use_rccl) ? 1 : 0; }
@@ -116,11 +121,17 @@ int lj_group_scene_upload(lj_device_group *group, const LjSceneDesc *desc, lj_gr
             if (rc != LJ_OK) throw LjError(rc, lj_last_error());
             gs->scene.push_back(s);
         }
+        group->live_scenes++;
         *out = gs.release();
     });
 }
 
-void lj_group_scene_destroy(lj_group_scene *scene) { delete scene; }
+void lj_group_scene_destroy(lj_group_scene *scene) {
+    if (!scene) return;
+    lj_device_group *g = scene->group;
+    delete scene;
+    if (--g->live_scenes == 0 && g->doomed) lj_group_destroy(g);
+}
 lj_scene *lj_group_scene_member(lj_group_scene *scene, int i) { return (scene && i >= 0 && i < (int)scene->scene.size()) ? scene->scene[i] : nullptr; }
 
 int lj_group_render(lj_group_scene *gs, const LjRenderArgs *args, float *rgb_host) {
@@ -149,7 +160,9 @@ int lj_group_render(lj_group_scene *gs, const LjRenderArgs *args, float *rgb_hos
         // ---- one sum-reduce of the float frames onto device 0
         if (g->use_rccl) {
             RCCL_CHECK(rccl().GroupStart());
-            for (int i = 0; i < n; i++) RCCL_CHECK(rccl().Reduce(g->frame[i]->p, g->frame[0]->p, count, ncclFloat, ncclSum, 0, g->comm[i], g->ctx[i]->stream));
+            try {
+                for (int i = 0; i < n; i++) RCCL_CHECK(rccl().Reduce(g->frame[i]->p, g->frame[0]->p, count, ncclFloat, ncclSum, 0, g->comm[i], g->ctx[i]->stream));
+            } catch (...) { (void)rccl().GroupEnd(); throw; }   // never leave the group call open
             RCCL_CHECK(rccl().GroupEnd());
         } else if (n > 1) {
             lj_context *c0 = g->ctx[0];

@@ -663,12 +663,40 @@ __global__ void __launch_bounds__(kBlock) k_resolve(DPass pass, uint32_t n_pixel
 
 // ---------------------------------------------------------------- batched ray queries for the parity tests
 
-// (wave-complete iterations over the rays and the same two phases as k_extend — inner nodes lane by lane, leaves pooled — so that the
-// parity tests of intersect() / occluded() hold the pooled leaf phase to the oracle, bit for bit)
+// Closest hit (or any hit) of every lane's ray, the whole wave together, with k_extend's two phases — inner nodes lane by lane while enough
+// lanes descend, leaves pooled.  L: set up by trav_begin (lanes without a ray: L.cur = kDone).  Ends with trav_finish.
+__device__ __forceinline__ void trace_wave(const TreeView &tv, const LeafPool &lp, LaneTrav &L, const bool any_hit) {
+#if LJ_EXT_POOL
+    for (;;) {
+        for (;;) {
+#if LJ_EXT_HOLD && LJ_EXT_POOL
+            if (L.cur < 0 && L.held == 0) trav_hold<false>(tv, L);
+#endif
+            const bool descending = L.cur >= 0 && L.cur != kDone;
+            if (__ballot(descending) == 0ull) break;
+            if (descending) trav_node_step<false>(tv, L);
+        }
+        const bool at_leaf = L.cur < 0 || L.held != 0;
+        if (__ballot(at_leaf) == 0ull) break;
+        uint32_t n_pairs;
+        (void)trav_leaf_pool<false, true>(tv, lp, L, at_leaf, any_hit, n_pairs);
+    }
+#else
+    while (L.cur != kDone) {
+        while (L.cur >= 0 && L.cur != kDone) trav_node_step<false>(tv, L);
+        if (L.cur < 0) trav_leaf_step<false, true>(tv, L, any_hit);
+    }
+#endif
+    trav_finish(L);
+}
+
+// (wave-complete iterations over the rays, traced by trace_wave: the parity tests of intersect() / occluded() hold the pooled leaf phase
+// to the oracle, bit for bit)
 __global__ void __launch_bounds__(kBlock) k_trace_rays(DScene sc, const RayIO *rays, long long n, HitIO *hits, unsigned char *occ, int stack, int lds_nodes, int lds_prims, int *spill, uint32_t pool_at) {
     const TreeView tv = stage_tree(sc, stack, lds_nodes, lds_prims, spill, gridDim.x * kBlock, blockIdx.x * kBlock + threadIdx.x);
+    LeafPool lp{};
 #if LJ_EXT_POOL
-    const LeafPool lp = leaf_pool_at(pool_at);
+    lp = leaf_pool_at(pool_at);
 #endif
     for (long long i0 = (long long)blockIdx.x * kBlock; i0 < n; i0 += (long long)gridDim.x * kBlock) {
         const long long i = i0 + threadIdx.x;
@@ -681,28 +709,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_rays(DScene sc, const RayIO *r
         }
         trav_begin(L, act ? rays[i].tnear : 0.0f, act ? rays[i].tfar : 0.0f);
         if (!act) L.cur = kDone;
-#if LJ_EXT_POOL
-        for (;;) {
-            for (;;) {
-#if LJ_EXT_HOLD && LJ_EXT_POOL
-                if (L.cur < 0 && L.held == 0) trav_hold<false>(tv, L);
-#endif
-                const bool descending = L.cur >= 0 && L.cur != kDone;
-                if (__ballot(descending) == 0ull) break;
-                if (descending) trav_node_step<false>(tv, L);
-            }
-            const bool at_leaf = L.cur < 0 || L.held != 0;
-            if (__ballot(at_leaf) == 0ull) break;
-            uint32_t n_pairs;
-            (void)trav_leaf_pool<false, true>(tv, lp, L, at_leaf, occ != nullptr, n_pairs);
-        }
-#else
-        while (L.cur != kDone) {
-            while (L.cur >= 0 && L.cur != kDone) trav_node_step<false>(tv, L);
-            if (L.cur < 0) trav_leaf_step<false, true>(tv, L, occ != nullptr);
-        }
-#endif
-        trav_finish(L);
+        trace_wave(tv, lp, L, occ != nullptr);
         if (!act) continue;
         if (occ) occ[i] = L.best.gprim >= 0 ? 1 : 0;
         else {
@@ -739,15 +746,32 @@ __global__ void __launch_bounds__(kBlock) k_aux(DScene sc, const uint32_t *pixel
 
 // ---------------------------------------------------------------- volumetric path tracer (dvol.h)
 // One lane walks one camera sample's whole path; closest hits come from the same traversal steps the extend kernel uses.
+// LJ_VOLPATH_STATS (a developer build, tools/dev/volpath_stats.sh): wave-level counts of how often each part of the volumetric tracer
+// runs and how many lanes are active in it — slots: 0 traversal node iterations, 1 leaf steps, 2 closest() calls, 3 / 4 tracking iterations
+// of the bounce loop / of shadow segments, 5 shadow segments, 6 vol_path_step calls.  counters[4 + 2 s], [5 + 2 s] (64 bit): events, lanes.
+#ifndef LJ_VOLPATH_STATS
+#define LJ_VOLPATH_STATS 0
+#endif
 struct DevTracer {
     const TreeView &tv;
+#if LJ_VOLPATH_STATS
+    uint32_t ev[8], ln[8];   // ln: events this lane was active in; ev: events this lane was the first active lane of (their sum over a wave = the wave's events)
+    __device__ __forceinline__ void tick(int s) {
+        const unsigned long long b = __ballot(true);
+        ln[s]++;
+        if (__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u)) == 0u) ev[s]++;
+    }
+#else
+    __device__ __forceinline__ void tick(int) {}
+#endif
     __device__ __forceinline__ bool closest(f3 org, f3 dir, float tnear, float tfar, float &t, float &u, float &v, int &gprim) {
         LaneTrav L;
         L.ray.ox = org.x; L.ray.oy = org.y; L.ray.oz = org.z; L.ray.dx = dir.x; L.ray.dy = dir.y; L.ray.dz = dir.z;
         trav_begin(L, tnear, tfar);
+        tick(2);
         while (L.cur != kDone) {
-            while (L.cur >= 0 && L.cur != kDone) trav_node_step<false>(tv, L);
-            if (L.cur < 0) trav_leaf_step<false, true>(tv, L, false);
+            while (L.cur >= 0 && L.cur != kDone) { tick(0); trav_node_step<false>(tv, L); }
+            if (L.cur < 0) { tick(1); trav_leaf_step<false, true>(tv, L, false); }
         }
         trav_finish(L);
         if (L.best.gprim < 0) return false;
@@ -764,6 +788,9 @@ struct DevTracer {
 __device__ __forceinline__ void volpath_body(const DScene &sc, const DPass &pass, uint32_t n_samples, uint32_t grab, uint32_t *counters, int stack, int lds_nodes, int lds_prims, int *spill) {
     const TreeView tv = stage_tree(sc, stack, lds_nodes, lds_prims, spill, gridDim.x * kBlock, blockIdx.x * kBlock + threadIdx.x);
     DevTracer tr{tv};
+#if LJ_VOLPATH_STATS
+    for (int k = 0; k < 8; k++) { tr.ev[k] = 0; tr.ln[k] = 0; }
+#endif
     uint32_t *sample_counter = counters + 2;
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t bounces = 0;
@@ -804,11 +831,18 @@ __device__ __forceinline__ void volpath_body(const DScene &sc, const DPass &pass
         if (__ballot(live) == 0ull) { if (exhausted) break; else continue; }
         if (live) {
             f3 rad;
+            tr.tick(6);
             if (!vol_path_step(sc, tr, P, rad)) { finish(sample, rad, P.bounce_iterations); live = false; }
         }
     }
     const uint32_t wb = wave_sum(bounces);
     if (lane == 0u && wb) atomicAdd((unsigned long long *)counters, (unsigned long long)wb);
+#if LJ_VOLPATH_STATS
+    for (int k = 0; k < 8; k++) {
+        const uint32_t e = wave_sum(tr.ev[k]), l = wave_sum(tr.ln[k]);
+        if (lane == 0u) { atomicAdd((unsigned long long *)counters + 2 + 2 * k, (unsigned long long)e); atomicAdd((unsigned long long *)counters + 3 + 2 * k, (unsigned long long)l); }
+    }
+#endif
 }
 // Two builds of the same body.  Unconstrained it takes ~250 VGPRs (two waves per SIMD); built for three waves (168, some spilled) the
 // scenes with homogeneous media run faster, but a heterogeneous medium — whose tracker keeps the grid-lookup state live through long

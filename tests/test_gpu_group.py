@@ -54,3 +54,46 @@ def test_rccl_binding_with_a_one_rank_communicator():
     got = lj.render_group(gs, spp=2)
     want = lj.render(lj.Scene(lj.Context(0), hs), spp=2)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_several_distinct_devices_with_and_without_rccl():
+    """>= 2 visible devices only (the driver's multi-GPU node; skipped on the one-GPU box): the group image through RCCL's grouped
+    ncclReduce and through the RCCL-free peer-copy + device sum must both equal the single-device frame bit for bit."""
+    import torch
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip("needs at least two visible devices")
+    n = min(n, 4)
+    hs = lj.parse_scene(scene_path("cbox"))
+    want = lj.render(lj.Scene(lj.Context(0), hs), spp=4)
+    for no_rccl in ("0", "1"):
+        os.environ["LJ_GROUP_NO_RCCL"] = no_rccl
+        try:
+            g = lj.DeviceGroup(list(range(n)))
+        finally:
+            os.environ.pop("LJ_GROUP_NO_RCCL", None)
+        assert g.uses_rccl == (no_rccl == "0")
+        got = lj.render_group(lj.GroupScene(g, hs), spp=4)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), no_rccl
+
+
+def test_handles_may_be_destroyed_in_any_order():
+    """The C ABI's lifetime rule (lajolla_hip.h): a context or group destroyed before its scenes is released by the last scene."""
+    import ctypes as C
+    lib = lj.load_library()
+    hs = lj.parse_scene(scene_path("cbox"))
+    ctx, sc = C.c_void_p(), C.c_void_p()
+    assert lib.lj_context_create(0, C.byref(ctx)) == 0
+    assert lib.lj_scene_upload(ctx, hs.desc_ptr, C.byref(sc)) == 0
+    lib.lj_context_destroy(ctx)                       # first the context ...
+    img = np.zeros((hs.height, hs.width, 3), np.float32)
+    args = lj.make_args(spp=1)
+    assert lib.lj_render(sc, C.byref(args), img.ctypes.data_as(C.c_void_p)) == 0 and img.any()   # ... the scene still renders
+    lib.lj_scene_destroy(sc)                          # ... and takes the context with it
+    grp, gs = C.c_void_p(), C.c_void_p()
+    ids = (C.c_int * 2)(0, 0)
+    assert lib.lj_group_create(2, ids, C.byref(grp)) == 0
+    assert lib.lj_group_scene_upload(grp, hs.desc_ptr, C.byref(gs)) == 0
+    lib.lj_group_destroy(grp)
+    assert lib.lj_group_render(gs, C.byref(args), img.ctypes.data_as(C.c_void_p)) == 0
+    lib.lj_group_scene_destroy(gs)

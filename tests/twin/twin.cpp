@@ -79,6 +79,7 @@ struct Twin { lj::FlatScene flat; DScene view; };
 // what k_volpath's tracer does: one closest-hit query over the BVH
 struct HostTracer {
     const DScene &sc;
+    void tick(int) {}
     bool closest(f3 org, f3 dir, float tnear, float tfar, float &t, float &u, float &v, int &gprim) {
         HostMem mem(sc);
         RayF ray; ray.ox = org.x; ray.oy = org.y; ray.oz = org.z; ray.dx = dir.x; ray.dy = dir.y; ray.dz = dir.z; ray.tnear = tnear; ray.tfar = tfar;
