@@ -26,7 +26,7 @@ ORACLE_LIB = os.path.join(ROOT, "oracle", "_build", "liblj_oracle_asan.so" if _S
 TWIN_LIB = os.path.join(ROOT, "tests", "twin", "_build", "libljtwin_asan.so" if _SAN else "libljtwin.so")
 
 HOST_SOURCES = ["host/api_host.cpp", "host/scene_xml.cpp", "host/mesh_io.cpp", "host/image_io.cpp", "host/jpeg_decode.cpp", "host/exr_decode.cpp", "host/png_decode.cpp", "host/tga_bmp_decode.cpp", "host/flatten.cpp", "host/bvh.cpp"]
-HIP_SOURCES = ["device/kernels.hip", "device/extend8.hip", "device/api_device.hip", "device/queries.hip", "device/mega.hip", "device/group.hip"]
+HIP_SOURCES = ["device/kernels.hip", "device/extend8.hip", "device/volpath.hip", "device/api_device.hip", "device/queries.hip", "device/mega.hip", "device/group.hip"]
 ARCH = "gfx950"
 
 

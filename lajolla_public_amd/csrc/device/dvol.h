@@ -108,12 +108,13 @@ struct VolRng { uint64_t state, inc; };
 LJ_HD float vrnd(VolRng &r) { return pcg32_real(r.state, r.inc); }
 
 // next_event_estimation_final (vol_path_tracing.h:299-494)
-template <class Tracer>
+// Ft: the scene's feature set (dshade.h) — the kernel is instantiated per set, so that a scene of diffuse surfaces does not carry nine BSDFs
+template <class Ft, class Tracer>
 LJ_HD f3 vol_nee(const DScene &sc, Tracer &tr, VolRng &rng, f3 p, int current_medium, int bounces, f3 dir_view, bool is_surface, const DVertex &vertex) {
     const float lu0 = vrnd(rng), lu1 = vrnd(rng), light_w = vrnd(rng), shape_w = vrnd(rng);
     const int light_id = sample_cdf(sc.light_cdf, sc.n_lights, light_w);
     const DLight &Lt = sc.lights[light_id];
-    const LightSample pl = sample_point_on_light(sc, Lt, p, lu0, lu1, shape_w);
+    const LightSample pl = sample_point_on_light<Ft>(sc, Lt, p, lu0, lu1, shape_w);
     // direction and distances from the double sample point (LightSample, dshade.h): exact on a sphere light
     auto dist_to = [&](f3 from) {
         const double dx = pl.dpos[0] - (double)from.x, dy = pl.dpos[1] - (double)from.y, dz = pl.dpos[2] - (double)from.z;
@@ -176,14 +177,14 @@ LJ_HD f3 vol_nee(const DScene &sc, Tracer &tr, VolRng &rng, f3 p, int current_me
         p = p + dir_light * next_t;
     }
     if (!(max3(T) > 0.0f)) return mk3(0, 0, 0);
-    const f3 Le = light_emission(sc, Lt, -dir_light, pl.normal);
+    const f3 Le = light_emission<Ft>(sc, Lt, -dir_light, pl.normal);
     const f3 dpl = p_origin - p_prime;
     const float jacobian = fmaxf(-dot(dir_light, pl.normal), 0.0f) / dot(dpl, dpl);
-    const f3 pdf_nee = p_trans_nee * (Lt.pmf * pdf_point_on_light(sc, Lt, pl.position, pl.normal, p_origin));
+    const f3 pdf_nee = p_trans_nee * (Lt.pmf * pdf_point_on_light<Ft>(sc, Lt, pl.position, pl.normal, p_origin));
     f3 f, pdf_dir;
     if (is_surface) {
         float pdf_bsdf;
-        bsdf_eval_pdf(sc, sc.materials[vertex.material_id], dir_view, dir_light, vertex, f, pdf_bsdf);
+        bsdf_eval_pdf<Ft>(sc, sc.materials[vertex.material_id], dir_view, dir_light, vertex, f, pdf_bsdf);
         if (pdf_bsdf <= 0.0f) return mk3(0, 0, 0);
         pdf_dir = p_trans_dir * (pdf_bsdf * jacobian);
     } else {
@@ -199,7 +200,7 @@ LJ_HD f3 vol_nee(const DScene &sc, Tracer &tr, VolRng &rng, f3 p, int current_me
 }
 
 // vol_path_tracing_1 (vol_path_tracing.h:6-41): absorption only — a directly visible emitter through the exterior medium of its surface
-template <class Tracer>
+template <class Ft, class Tracer>
 LJ_HD f3 vol_path_sample_1(const DScene &sc, Tracer &tr, int x, int y, VolRng &rng) {
     const float jy = vrnd(rng), jx = vrnd(rng);
     const f3 org = ld3(sc.cam.org), dir = camera_primary_dir(sc.cam, x, y, jx, jy);
@@ -212,13 +213,13 @@ LJ_HD f3 vol_path_sample_1(const DScene &sc, Tracer &tr, int x, int y, VolRng &r
     f3 sigma_s, sigma_a; get_sigmas(sc, sc.media[exterior], vertex.position, sigma_s, sigma_a);
     const f3 transmittance = vexp3(-(sigma_a * t_hit));
     f3 Le = mk3(0, 0, 0);
-    if (vertex.light_id >= 0) Le = light_emission(sc, sc.lights[vertex.light_id], -dir, vertex.gn);
+    if (vertex.light_id >= 0) Le = light_emission<Ft>(sc, sc.lights[vertex.light_id], -dir, vertex.gn);
     return transmittance * Le;
 }
 
 // vol_path_tracing_2 (vol_path_tracing.h:46-147): one monochromatic homogeneous medium, single scattering, free flight on the red channel
 // (oracle/lj_oracle.cpp vol_path_tracing_2 lists what is kept of the reference's reading of an empty optional)
-template <class Tracer>
+template <class Ft, class Tracer>
 LJ_HD f3 vol_path_sample_2(const DScene &sc, Tracer &tr, int x, int y, VolRng &rng) {
     const float jy = vrnd(rng), jx = vrnd(rng);
     const f3 org = ld3(sc.cam.org), dir = camera_primary_dir(sc.cam, x, y, jx, jy);
@@ -240,20 +241,20 @@ LJ_HD f3 vol_path_sample_2(const DScene &sc, Tracer &tr, int x, int y, VolRng &r
         const float lu0 = vrnd(rng), lu1 = vrnd(rng), light_w = vrnd(rng), shape_w = vrnd(rng);
         const int light_id = sample_cdf(sc.light_cdf, sc.n_lights, light_w);
         const DLight &Lt = sc.lights[light_id];
-        const LightSample pl = sample_point_on_light(sc, Lt, p, lu0, lu1, shape_w);
+        const LightSample pl = sample_point_on_light<Ft>(sc, Lt, p, lu0, lu1, shape_w);
         // (direction and distance from the double sample point, as in vol_nee)
         const double dx = pl.dpos[0] - (double)p.x, dy = pl.dpos[1] - (double)p.y, dz = pl.dpos[2] - (double)p.z;
         const double dist_d = sqrt(dx * dx + dy * dy + dz * dz);
         const f3 dir_light = mk3((float)(dx / dist_d), (float)(dy / dist_d), (float)(dz / dist_d));
         const float dist = (float)dist_d;
         const float rho = phase_eval(med, -dir, dir_light);
-        const f3 Le = light_emission(sc, Lt, -dir_light, pl.normal);
+        const f3 Le = light_emission<Ft>(sc, Lt, -dir_light, pl.normal);
         const f3 exp_term = vexp3(-(sigma_t * dist));
         float st, su, sv; int sg;
         const float visibility = tr.closest(p, dir_light, sc.eps, (float)((1.0 - (double)sc.eps) * dist_d), st, su, sv, sg) ? 0.0f : 1.0f;
         const float jacobian = fabsf(dot(dir_light, pl.normal)) / (float)(dist_d * dist_d) * visibility;
         const f3 L_s1 = Le * rho * exp_term * jacobian;
-        const float L_s1_pdf = Lt.pmf * pdf_point_on_light(sc, Lt, pl.position, pl.normal, p);
+        const float L_s1_pdf = Lt.pmf * pdf_point_on_light<Ft>(sc, Lt, pl.position, pl.normal, p);
         return vdiv3(transmittance, trans_pdf) * sigma_s * (L_s1 / L_s1_pdf);
     }
     // a ray that left the scene has no vertex to take an emission from (this arm is reached for it when sigma_t.x is 0 at the ray origin:
@@ -261,7 +262,7 @@ LJ_HD f3 vol_path_sample_2(const DScene &sc, Tracer &tr, int x, int y, VolRng &r
     if (!hit) return mk3(0, 0, 0);
     const f3 transmittance = vexp3(-(sigma_t * t_hit));   // (the pdf is the same expression: the ratio is 1, or 0 / 0 once it underflows)
     f3 Le = mk3(0, 0, 0);
-    if (vertex.light_id >= 0) Le = light_emission(sc, sc.lights[vertex.light_id], -dir, vertex.gn);
+    if (vertex.light_id >= 0) Le = light_emission<Ft>(sc, sc.lights[vertex.light_id], -dir, vertex.gn);
     return vdiv3(transmittance, transmittance) * Le;
 }
 
@@ -283,12 +284,12 @@ struct VolPath {
     int guard;                          // Russian roulette ends a path with probability >= 5 % per iteration past rr_depth; the cap bounds rr_depth = huge
 };
 // returns false when the sample is already finished (`result`): versions 1 and 2 are single-shot estimators
-template <class Tracer>
+template <class Ft, class Tracer>
 LJ_HD bool vol_path_begin(const DScene &sc, Tracer &tr, int x, int y, uint64_t stream, uint64_t seed, VolPath &P, f3 &result) {
     P.rng.inc = pcg32_inc(stream); P.rng.state = pcg32_init(stream, seed);
     P.bounce_iterations = 0; P.guard = 0;
-    if (sc.vol_path_version == 1) { result = vol_path_sample_1(sc, tr, x, y, P.rng); return false; }
-    if (sc.vol_path_version == 2) { result = vol_path_sample_2(sc, tr, x, y, P.rng); return false; }
+    if (sc.vol_path_version == 1) { result = vol_path_sample_1<Ft>(sc, tr, x, y, P.rng); return false; }
+    if (sc.vol_path_version == 2) { result = vol_path_sample_2<Ft>(sc, tr, x, y, P.rng); return false; }
     const float jy = vrnd(P.rng), jx = vrnd(P.rng);
     P.org = ld3(sc.cam.org); P.dir = camera_primary_dir(sc.cam, x, y, jx, jy);
     P.spread = 0.0f;
@@ -301,7 +302,7 @@ LJ_HD bool vol_path_begin(const DScene &sc, Tracer &tr, int x, int y, uint64_t s
     return true;
 }
 // one iteration of the loop; false: the path has ended with `result`
-template <class Tracer>
+template <class Ft, class Tracer>
 LJ_HD bool vol_path_step(const DScene &sc, Tracer &tr, VolPath &P, f3 &result) {
     VolRng &rng = P.rng;
     f3 &org = P.org, &dir = P.dir; float &spread = P.spread;
@@ -365,9 +366,9 @@ LJ_HD bool vol_path_step(const DScene &sc, Tracer &tr, VolPath &P, f3 &result) {
     throughput = throughput * (transmittance / vavg3(trans_dir_pdf));
     if (!scatter && hit && vertex.light_id >= 0) {
         const DLight &EL = sc.lights[vertex.light_id];
-        const f3 Le = light_emission(sc, EL, -dir, vertex.gn);
+        const f3 Le = light_emission<Ft>(sc, EL, -dir, vertex.gn);
         if (bounces == 0) { result = radiance + throughput * Le; return false; }
-        const f3 pdf_nee = trans_nee_pdf * (EL.pmf * pdf_point_on_light(sc, EL, vertex.position, vertex.gn, nee_p_cache));
+        const f3 pdf_nee = trans_nee_pdf * (EL.pmf * pdf_point_on_light<Ft>(sc, EL, vertex.position, vertex.gn, nee_p_cache));
         const f3 dv = nee_p_cache - vertex.position;
         const float jacobian = fmaxf(-dot(-dir, vertex.gn), 0.0f) / dot(dv, dv);
         const f3 pdf_phase = multi_trans_pdf * (dir_pdf * jacobian);
@@ -385,7 +386,7 @@ LJ_HD bool vol_path_step(const DScene &sc, Tracer &tr, VolPath &P, f3 &result) {
     if (scatter && current_medium != -1) {
         const DMedium &med = sc.media[current_medium];
         f3 sigma_s, sigma_a; get_sigmas(sc, med, org, sigma_s, sigma_a);
-        const f3 nee = vol_nee(sc, tr, rng, org, current_medium, bounces, -dir, false, vertex);
+        const f3 nee = vol_nee<Ft>(sc, tr, rng, org, current_medium, bounces, -dir, false, vertex);
         radiance = radiance + throughput * sigma_s * nee;
         if (max3(nee) > 0.0f) nee_p_cache = org;
         const float r0 = vrnd(rng), r1 = vrnd(rng);
@@ -396,13 +397,13 @@ LJ_HD bool vol_path_step(const DScene &sc, Tracer &tr, VolPath &P, f3 &result) {
         dir_pdf = phase_pdf;
         multi_trans_pdf = mk3(1, 1, 1);
     } else if (hit) {
-        const f3 nee = vol_nee(sc, tr, rng, org, current_medium, bounces, -dir, true, vertex);
+        const f3 nee = vol_nee<Ft>(sc, tr, rng, org, current_medium, bounces, -dir, true, vertex);
         radiance = radiance + throughput * nee;
         if (max3(nee) > 0.0f) nee_p_cache = org;
         const DMaterial &mat = sc.materials[vertex.material_id];
         const f3 dir_view = -dir;
         const float b0 = vrnd(rng), b1 = vrnd(rng), bw = vrnd(rng);
-        const BsdfSample bs = bsdf_sample(sc, mat, dir_view, vertex, b0, b1, bw);
+        const BsdfSample bs = bsdf_sample<Ft>(sc, mat, dir_view, vertex, b0, b1, bw);
         if (!bs.valid) { result = radiance; return false; }
         dir = bs.dir_out;
         if (bs.eta == 0.0f) spread = fmaxf(spread * (1.0f - bs.roughness) + 0.2f * bs.roughness, 0.0f);
@@ -412,7 +413,7 @@ LJ_HD bool vol_path_step(const DScene &sc, Tracer &tr, VolPath &P, f3 &result) {
             current_medium = update_medium(sc, vertex, dir, current_medium);
         }
         f3 f; float pdf_bsdf;
-        bsdf_eval_pdf(sc, mat, dir_view, bs.dir_out, vertex, f, pdf_bsdf);
+        bsdf_eval_pdf<Ft>(sc, mat, dir_view, bs.dir_out, vertex, f, pdf_bsdf);
         throughput = throughput * (f / pdf_bsdf);
     }
     if (bounces >= sc.rr_depth) {
@@ -423,12 +424,12 @@ LJ_HD bool vol_path_step(const DScene &sc, Tracer &tr, VolPath &P, f3 &result) {
     bounces++;
     return true;
 }
-template <class Tracer>
+template <class Ft = FeatAll, class Tracer>
 LJ_HD f3 vol_path_sample(const DScene &sc, Tracer &tr, int x, int y, uint64_t stream, uint64_t seed, uint32_t &bounces_out) {
     VolPath P; f3 result = mk3(0, 0, 0);
     bounces_out = 0;
-    if (!vol_path_begin(sc, tr, x, y, stream, seed, P, result)) return result;
-    while (vol_path_step(sc, tr, P, result)) {}
+    if (!vol_path_begin<Ft>(sc, tr, x, y, stream, seed, P, result)) return result;
+    while (vol_path_step<Ft>(sc, tr, P, result)) {}
     bounces_out = P.bounce_iterations;
     return result;
 }

@@ -20,10 +20,9 @@
 #include <cstdlib>
 #include <algorithm>
 #include "dstage.h"
-#include "dvol.h"
 #include "dtrace.h"
 #include "dconfig.h"
-#include "dpool.h"
+#include "dtrav.h"
 
 namespace ljd {
 
@@ -48,258 +47,7 @@ __device__ __forceinline__ void q_store(const DQueue &q, uint32_t i, const PathS
     q.rg[i] = mk4(u2f(ps.sample), u2f((uint32_t)ps.rng), u2f((uint32_t)(ps.rng >> 32)), ps.p2);
 }
 
-// ---------------------------------------------------------------- extend
-// LDS image (dynamic): [ per-lane stacks: cap x 256 ints ][ first n_lnodes BVH4 nodes ][ first n_lprims leaf prims ]
-// Nodes are stored breadth-first, so a prefix of the node array is the top of the tree.
-struct TreeView {
-    const char *gnodes; const v4f *gprims; const DSphere *spheres;
-    const LJ_LDS char *lnodes; const LJ_LDS v4f *lprims;
-    LJ_LDS int *stack;   // this lane's column; level l lives at stack[l * kBlock]
-    int *spill;          // this lane's column of the overflow stack in global memory (levels >= cap), stride spill_stride
-    uint32_t spill_stride;
-    int n_lnodes, n_lprims, prim_stride, cap;
-    uint32_t qstride;    // bytes between two quarters of one node in the LDS image (= staged nodes * 16)
-};
-
-
-__device__ __forceinline__ TreeView stage_tree(const DScene &sc, int stack, int lds_nodes, int lds_prims, int *spill, uint32_t spill_stride, uint32_t lane_global) {
-    TreeView tv;
-    LJ_LDS v4f *base = (LJ_LDS v4f *)lj_smem;
-    tv.stack = (LJ_LDS int *)base + threadIdx.x;
-    tv.cap = stack;
-    tv.spill = spill + lane_global; tv.spill_stride = spill_stride;
-    LJ_LDS v4f *ln = base + (stack * kBlock) / 4;
-    LJ_LDS v4f *lp = ln + lds_nodes * 7;
-    tv.n_lnodes = sc.n_nodes < lds_nodes ? sc.n_nodes : lds_nodes;
-    tv.n_lprims = sc.n_prims < lds_prims ? sc.n_prims : lds_prims;
-    tv.qstride = (uint32_t)lds_nodes * 16u; tv.prim_stride = lds_prims;
-    // The LDS image is transposed: quarter k of node i sits at ln[k * lds_nodes + i].  Lanes that fetch different
-    // nodes then hit different 16-byte bank slots (a 128-byte stride would put every node on the same four).
-    const v4f *src = reinterpret_cast<const v4f *>(sc.nodes);
-    for (int i = threadIdx.x; i < tv.n_lnodes * 7; i += kBlock) { const int node = i / 7, k = i - node * 7; ln[k * lds_nodes + node] = src[node * 8 + k]; }
-    src = reinterpret_cast<const v4f *>(sc.leaf_prims);
-    for (int i = threadIdx.x; i < tv.n_lprims * 3; i += kBlock) lp[(i % 3) * lds_prims + (i / 3)] = src[i];
-    __syncthreads();
-    tv.gnodes = reinterpret_cast<const char *>(sc.nodes); tv.gprims = reinterpret_cast<const v4f *>(sc.leaf_prims);
-    tv.spheres = sc.spheres; tv.lnodes = (const LJ_LDS char *)ln; tv.lprims = lp;
-    return tv;
-}
-
-constexpr int kDone = 0x7fffffff;  // "no more work for this ray" marker in `cur`
-
-struct LaneTrav {
-    RayF ray;
-    // slab constants: t = fma(plane, i, -oi) with i = 1 / d, oi = o * i
-    float ix, iy, iz, oix, oiy, oiz;
-    HitRec best;     // for a triangle hit u, v hold the unnormalised barycentrics U, V until trav_finish divides by best_S
-    float best_S;
-    int cur, sp;
-    int held;        // a leaf this ray has reached but not tested yet (0: none) — see trav_hold
-    uint32_t nqx, nqy, nqz;  // quarter index (0..5) holding the NEAR plane of each axis for this ray's direction signs
-};
-
-__device__ __forceinline__ void trav_begin(LaneTrav &L, float tnear, float tfar) {
-    L.ray.tnear = tnear; L.ray.tfar = tfar;
-    // v_rcp_f32 (1 ulp) is enough here: the slabs only steer the traversal, and the boxes carry a 1e-5 pad plus a 4-ulp
-    // widening of the exit distance; hits are decided by the primitive tests alone
-    L.ix = __builtin_amdgcn_rcpf(L.ray.dx); L.iy = __builtin_amdgcn_rcpf(L.ray.dy); L.iz = __builtin_amdgcn_rcpf(L.ray.dz);
-    // One fma per plane instead of subtract + multiply.  (plane - o) * i is exact where plane ~ o and the fma is not, but
-    // its error there, ulp(o * i), is a hundredth of what the builder's 1e-5 box padding amounts to in t; away from that
-    // both forms carry the same rounding of o.  A direction component of 0 gives i = inf and o * i = inf or nan: the
-    // planes of that axis then all read nan, which fmax / fmin ignore — the axis drops out of the test (conservative).
-    L.oix = L.ray.ox * L.ix; L.oiy = L.ray.oy * L.iy; L.oiz = L.ray.oz * L.iz;
-    L.nqx = L.ix < 0.0f ? 3u : 0u; L.nqy = L.iy < 0.0f ? 4u : 1u; L.nqz = L.iz < 0.0f ? 5u : 2u;
-    L.best.t = tfar; L.best.u = 0.0f; L.best.v = 0.0f; L.best.gprim = -1; L.best_S = 1.0f;
-    L.cur = 0; L.sp = 0; L.held = 0;
-}
-__device__ __forceinline__ void trav_push(const TreeView &tv, LaneTrav &L, int v) {
-    if (L.sp < tv.cap) tv.stack[L.sp * kBlock] = v;
-    else tv.spill[(uint32_t)(L.sp - tv.cap) * tv.spill_stride] = v;
-    L.sp++;
-}
-template <bool RESIDENT = false>
-__device__ __forceinline__ int trav_pop(const TreeView &tv, LaneTrav &L) {
-    // every level (of the lanes that pop here) is in LDS: one read, no branch (and no global load for the scheduler to wait on)
-    if (RESIDENT || __ballot(L.sp > tv.cap) == 0ull) {
-        const int sp = L.sp > 0 ? L.sp - 1 : 0;
-        const int v = tv.stack[sp * kBlock];
-        const int r = L.sp > 0 ? v : kDone;
-        L.sp = sp;
-        return r;
-    }
-    if (L.sp == 0) return kDone;
-    L.sp--;
-    if (L.sp < tv.cap) return tv.stack[L.sp * kBlock];
-    return tv.spill[(uint32_t)(L.sp - tv.cap) * tv.spill_stride];
-}
-
-// A ray that reaches a leaf sets it aside and goes on with the next entry of its stack; it only has to wait for the wave's leaf phase when
-// it reaches a second one.  The lanes of a wave then spend more node steps together before the leaf phase (which finds fuller rounds), at
-// the price of the node steps a hit in the held leaf would have culled.  The closest hit is the minimum of (t, primitive id) over
-// everything the ray tests, so the order of the tests cannot change it.
-#ifndef LJ_EXT_HOLD
-#define LJ_EXT_HOLD 1
-#endif
-#ifndef LJ_EXT_HOLD_SHADOW
-#define LJ_EXT_HOLD_SHADOW 1   // any-hit rays hold a leaf too (0: they wait at their first leaf — a hit there ends them)
-#endif
-template <bool RESIDENT>
-__device__ __forceinline__ void trav_hold(const TreeView &tv, LaneTrav &L) {
-    L.held = L.cur;
-    L.cur = trav_pop<RESIDENT>(tv, L);
-}
-
-// the one barycentric division of a closest-hit query (dtrace.h tri_test: u = U * (1 / S))
-__device__ __forceinline__ void trav_finish(LaneTrav &L) {
-    const float rS = div_ieee(1.0f, L.best_S);
-    L.best.u = L.best.u * rS; L.best.v = L.best.v * rS;
-}
-
-__device__ __forceinline__ void csw(float &ta, int &ca, float &tb, int &cb) {  // compare-exchange: nearer entry first
-    const bool sw = tb < ta;
-    const float t0 = sw ? tb : ta, t1 = sw ? ta : tb; const int c0 = sw ? cb : ca, c1 = sw ? ca : cb;
-    ta = t0; tb = t1; ca = c0; cb = c1;
-}
-
-// one inner-node step: slab-test the four children, continue with the nearest one that is hit, push the others far-first.
-// The stack part of the step is free of branches whenever the three pushes of every lane stay inside the LDS levels (always, when
-// the scene is RESIDENT — the whole tree and every stack level in LDS; else a wave-uniform test, which only a ray deeper than
-// `cap - 3` entries fails): the pushes store unconditionally and advance `sp` only for a hit, and the pop candidate is fetched with the node.
-#ifndef LJ_EXT_LDS_NODES
-#define LJ_EXT_LDS_NODES 1   // 0: a tree that is not fully LDS-resident is read through L1 / L2 only (no LDS copy of its top)
-#endif
-template <bool RESIDENT>
-__device__ __forceinline__ void trav_node_step(const TreeView &tv, LaneTrav &L) {
-    v4f nx, ny, nz, fx, fy, fz, ch;
-    const int i = L.cur;
-    int popped = kDone;
-    const bool fast = RESIDENT || __ballot(L.sp + 3 > tv.cap) == 0ull;
-    if (RESIDENT || (LJ_EXT_LDS_NODES && i < tv.n_lnodes)) {
-        const LJ_LDS char *b = tv.lnodes + (uint32_t)i * 16u;
-        const uint32_t S = tv.qstride;
-        nx = *(const LJ_LDS v4f *)(b + L.nqx * S); fx = *(const LJ_LDS v4f *)(b + (3u - L.nqx) * S);
-        ny = *(const LJ_LDS v4f *)(b + L.nqy * S); fy = *(const LJ_LDS v4f *)(b + (5u - L.nqy) * S);
-        nz = *(const LJ_LDS v4f *)(b + L.nqz * S); fz = *(const LJ_LDS v4f *)(b + (7u - L.nqz) * S);
-        ch = *(const LJ_LDS v4f *)(b + 6u * S);
-    } else {
-        const char *g = tv.gnodes;
-        const uint32_t o = (uint32_t)i * 128u;
-        nx = *(const v4f *)(g + (o + L.nqx * 16u)); fx = *(const v4f *)(g + (o + (3u - L.nqx) * 16u));
-        ny = *(const v4f *)(g + (o + L.nqy * 16u)); fy = *(const v4f *)(g + (o + (5u - L.nqy) * 16u));
-        nz = *(const v4f *)(g + (o + L.nqz * 16u)); fz = *(const v4f *)(g + (o + (7u - L.nqz) * 16u));
-        ch = *(const v4f *)(g + (o + 96u));
-    }
-    if (fast) popped = tv.stack[(L.sp > 0 ? L.sp - 1 : 0) * kBlock];
-    const float inf = __builtin_inff();
-
-    float t0[4]; int c[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const float te = fmaxf(fmaxf(__builtin_fmaf(nx[k], L.ix, -L.oix), __builtin_fmaf(ny[k], L.iy, -L.oiy)), fmaxf(__builtin_fmaf(nz[k], L.iz, -L.oiz), L.ray.tnear));
-        const float tx = fminf(fminf(__builtin_fmaf(fx[k], L.ix, -L.oix), __builtin_fmaf(fy[k], L.iy, -L.oiy)), fminf(__builtin_fmaf(fz[k], L.iz, -L.oiz), L.best.t));
-        t0[k] = (te <= tx * 1.0000005f) ? te : inf;
-        c[k] = __float_as_int(ch[k]);
-    }
-    // (an entry distance is finite for a hit: it is bounded by best.t or by the finite far planes)
-    csw(t0[0], c[0], t0[1], c[1]); csw(t0[2], c[2], t0[3], c[3]);
-    csw(t0[0], c[0], t0[2], c[2]); csw(t0[1], c[1], t0[3], c[3]);
-    csw(t0[1], c[1], t0[2], c[2]);
-    if (fast) {
-        const int sp0 = L.sp;
-        tv.stack[L.sp * kBlock] = c[3]; L.sp += (t0[3] < inf) ? 1 : 0;   // misses sort last: a slot written for a miss is
-        tv.stack[L.sp * kBlock] = c[2]; L.sp += (t0[2] < inf) ? 1 : 0;   // overwritten by the next store or never read
-        tv.stack[L.sp * kBlock] = c[1]; L.sp += (t0[1] < inf) ? 1 : 0;
-        const bool any = t0[0] < inf;
-        L.cur = any ? c[0] : (sp0 > 0 ? popped : kDone);
-        L.sp = any ? L.sp : (sp0 > 0 ? sp0 - 1 : 0);
-    } else {
-        if (t0[3] < inf) trav_push(tv, L, c[3]);
-        if (t0[2] < inf) trav_push(tv, L, c[2]);
-        if (t0[1] < inf) trav_push(tv, L, c[1]);
-        L.cur = (t0[0] < inf) ? c[0] : trav_pop(tv, L);
-    }
-}
-
-// one leaf: up to 8 primitives
-// SPHERES: the scene holds sphere shapes (their test is the reference's double-precision callback; a scene without
-// spheres should not even carry its set-up code).
-template <bool RESIDENT, bool SPHERES>
-__device__ __forceinline__ void trav_leaf_step(const TreeView &tv, LaneTrav &L, const bool ANY_HIT) {
-    const int code = ~L.cur;
-    const int first = code >> 3, count = (code & 7) + 1;
-    bool stop = false;
-    for (int k = 0; k < count && !stop; k++) {
-        const int pi = first + k;
-        v4f p0, p1, p2;
-        if (RESIDENT || pi < tv.n_lprims) { const int S = tv.prim_stride; p0 = tv.lprims[pi]; p1 = tv.lprims[S + pi]; p2 = tv.lprims[2 * S + pi]; }
-        else { p0 = tv.gprims[3 * pi]; p1 = tv.gprims[3 * pi + 1]; p2 = tv.gprims[3 * pi + 2]; }
-        const int gprim = __float_as_int(p0.w), kind = __float_as_int(p1.w);
-        if (!SPHERES || kind == 0) {
-            const float v0[3] = {p0.x, p0.y, p0.z}, v1[3] = {p1.x, p1.y, p1.z}, v2[3] = {p2.x, p2.y, p2.z};
-            float t = 0.0f, U = 0.0f, V = 0.0f, S = 1.0f;
-            const bool hit = tri_test_raw(L.ray, L.best.t, v0, v1, v2, t, U, V, S);
-            // selects, not branches: an any-hit ray only needs `gprim` (and stops), a closest-hit ray takes the nearer of
-            // (t, gprim); what the other fields of an any-hit ray hold no longer matters
-            const bool take = hit & (ANY_HIT | (t < L.best.t) | ((t == L.best.t) & ((L.best.gprim < 0) | (gprim < L.best.gprim))));
-            L.best.t = take ? t : L.best.t; L.best.u = take ? U : L.best.u; L.best.v = take ? V : L.best.v;
-            L.best_S = take ? S : L.best_S; L.best.gprim = take ? gprim : L.best.gprim;
-            stop = hit & ANY_HIT;
-        } else {
-            double td;
-            if (sphere_test(L.ray, tv.spheres[__float_as_int(p2.w)], td)) {
-                const float tf = (float)td;
-                // (selects here too: hipcc 7.2 mis-structurises the branch form `else if (a || (b && (c || d))) { five assignments }` —
-                // lanes that take the tie arm kept their old u, v)
-                const bool take = ANY_HIT | (tf < L.best.t) | ((tf == L.best.t) & ((L.best.gprim < 0) | (gprim < L.best.gprim)));
-                L.best.t = take ? tf : L.best.t; L.best.u = take ? 0.0f : L.best.u; L.best.v = take ? 0.0f : L.best.v;
-                L.best_S = take ? 1.0f : L.best_S; L.best.gprim = take ? gprim : L.best.gprim;
-                stop = ANY_HIT;
-            }
-        }
-    }
-    L.cur = stop ? kDone : trav_pop<RESIDENT>(tv, L);
-}
-
-// Called by the whole wave.  `at_leaf`: this lane's L.cur is a leaf.  Returns the number of
-// 64-pair rounds it ran (for the statistics); `n_pairs` the pairs.
-template <bool RESIDENT, bool SPHERES>
-__device__ __forceinline__ uint32_t trav_leaf_pool(const TreeView &tv, const LeafPool &lp, LaneTrav &L, const bool at_leaf, const bool any_hit, uint32_t &n_pairs) {
-    const uint32_t lane = threadIdx.x & 63u;
-    // this lane's leaves: the one it holds (A) and the one it sits on (B)
-    const int codeA = ~L.held, codeB = ~L.cur;
-    const int firstA = codeA >> 3, cntA = (at_leaf && L.held != 0) ? (codeA & 7) + 1 : 0;
-    const int firstB = codeB >> 3, cntB = (at_leaf && L.cur < 0) ? (codeB & 7) + 1 : 0;
-    const int count = cntA + cntB;
-    uint32_t rounds = 0;
-    n_pairs = 0;
-    for (int j = 0;;) {
-        // ---- list the pairs: pass j takes the j-th primitive of every leaf (neighbouring pairs then belong to different rays)
-        uint32_t n_items = 0;
-        for (;;) {
-            const bool has = count > j;
-            const unsigned long long b = __ballot(has);
-            if (b == 0ull || n_items + 64u > kPoolCap) break;
-            if (has) lp.items[n_items + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u))] = lane | ((uint32_t)(j < cntA ? firstA + j : firstB + (j - cntA)) << 6);
-            n_items += (uint32_t)__popcll(b); j++;
-        }
-        if (n_items == 0u) break;
-        n_pairs += n_items;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-        // ---- test them
-        pool_test_items<RESIDENT, SPHERES>(tv, lp, L, n_items, rounds);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-    }
-    // ---- every owner picks up its result
-    if (at_leaf) {
-        const bool stop = pool_collect(lp, L, any_hit);
-        const bool on_leaf = L.cur < 0;
-        L.held = 0;
-        if (stop) L.cur = kDone;
-        else if (on_leaf) L.cur = trav_pop<RESIDENT>(tv, L);
-    }
-    return rounds;
-}
-
+// ---------------------------------------------------------------- extend (the traversal steps live in dtrav.h)
 // STATS: developer instrumentation (LJ_EXTEND_STATS=1): wave-level step counts and the lanes active in them, summed into
 // stats[0..7] = {outer iterations, sum of busy lanes, node steps, lanes in node steps, leaf prim rounds, lanes in them,
 // refills, rays}.  The production instantiation carries none of it.
@@ -744,119 +492,6 @@ __global__ void __launch_bounds__(kBlock) k_aux(DScene sc, const uint32_t *pixel
     }
 }
 
-// ---------------------------------------------------------------- volumetric path tracer (dvol.h)
-// One lane walks one camera sample's whole path; closest hits come from the same traversal steps the extend kernel uses.
-// LJ_VOLPATH_STATS (a developer build, tools/dev/volpath_stats.sh): wave-level counts of how often each part of the volumetric tracer
-// runs and how many lanes are active in it — slots: 0 traversal node iterations, 1 leaf steps, 2 closest() calls, 3 / 4 tracking iterations
-// of the bounce loop / of shadow segments, 5 shadow segments, 6 vol_path_step calls.  counters[4 + 2 s], [5 + 2 s] (64 bit): events, lanes.
-#ifndef LJ_VOLPATH_STATS
-#define LJ_VOLPATH_STATS 0
-#endif
-struct DevTracer {
-    const TreeView &tv;
-#if LJ_VOLPATH_STATS
-    uint32_t ev[8], ln[8];   // ln: events this lane was active in; ev: events this lane was the first active lane of (their sum over a wave = the wave's events)
-    __device__ __forceinline__ void tick(int s) {
-        const unsigned long long b = __ballot(true);
-        ln[s]++;
-        if (__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u)) == 0u) ev[s]++;
-    }
-#else
-    __device__ __forceinline__ void tick(int) {}
-#endif
-    __device__ __forceinline__ bool closest(f3 org, f3 dir, float tnear, float tfar, float &t, float &u, float &v, int &gprim) {
-        LaneTrav L;
-        L.ray.ox = org.x; L.ray.oy = org.y; L.ray.oz = org.z; L.ray.dx = dir.x; L.ray.dy = dir.y; L.ray.dz = dir.z;
-        trav_begin(L, tnear, tfar);
-        tick(2);
-        while (L.cur != kDone) {
-            while (L.cur >= 0 && L.cur != kDone) { tick(0); trav_node_step<false>(tv, L); }
-            if (L.cur < 0) { tick(1); trav_leaf_step<false, true>(tv, L, false); }
-        }
-        trav_finish(L);
-        if (L.best.gprim < 0) return false;
-        t = L.best.t; u = L.best.u; v = L.best.v; gprim = L.best.gprim;
-        return true;
-    }
-};
-
-// Persistent waves with path regeneration (the structure of k_mega): every lane carries one path, bounce by bounce (dvol.h
-// vol_path_step); a lane whose path has ended takes the next camera sample of its wave's open range, and a wave whose range is used
-// up takes the next `grab` samples off one grid-wide counter — so the lanes of a wave stay busy whatever the lengths of their paths
-// (one whole path per lane left a wave waiting for its longest path).  A sample's value depends on its pcg32 stream only.
-// counters[0..1]: bounce iterations (64 bit); counters[2]: the sample counter (zeroed before the launch).
-__device__ __forceinline__ void volpath_body(const DScene &sc, const DPass &pass, uint32_t n_samples, uint32_t grab, uint32_t *counters, int stack, int lds_nodes, int lds_prims, int *spill) {
-    const TreeView tv = stage_tree(sc, stack, lds_nodes, lds_prims, spill, gridDim.x * kBlock, blockIdx.x * kBlock + threadIdx.x);
-    DevTracer tr{tv};
-#if LJ_VOLPATH_STATS
-    for (int k = 0; k < 8; k++) { tr.ev[k] = 0; tr.ln[k] = 0; }
-#endif
-    uint32_t *sample_counter = counters + 2;
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t bounces = 0;
-    bool live = false, exhausted = false;
-    uint32_t w_next = 0, w_end = 0;   // the wave's open range of camera samples (wave-uniform)
-    uint32_t sample = 0;
-    VolPath P;
-    auto finish = [&](uint32_t s, f3 rad, uint32_t nb) {
-        if (!(isfinite(rad.x) && isfinite(rad.y) && isfinite(rad.z))) rad = mk3(0, 0, 0);   // render.cpp:138-141: a non-finite sample is left out
-        float *o = pass.sample_rgb + 3ull * s;
-        o[0] = rad.x; o[1] = rad.y; o[2] = rad.z;
-        bounces += nb;
-    };
-    for (;;) {
-        const unsigned long long dead = __ballot(!live);
-        if (dead != 0ull && !exhausted) {
-            if (w_next == w_end) {
-                uint32_t b = 0;
-                if (lane == 0u) b = atomicAdd(sample_counter, grab);
-                b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-                if (b >= n_samples) exhausted = true;
-                else { w_next = b; w_end = (n_samples - b < grab) ? n_samples : b + grab; }
-            }
-            if (!exhausted) {
-                const uint32_t left = w_end - w_next, n_dead = (uint32_t)__popcll(dead);
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(dead >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dead, 0u));
-                if (!live && rank < left) {
-                    sample = w_next + rank;
-                    const uint32_t p = sample / pass.spp, k = sample - p * pass.spp;
-                    const uint32_t pixel = pass.pixel_list[p];
-                    f3 rad;
-                    live = vol_path_begin(sc, tr, (int)(pixel % (uint32_t)sc.cam.width), (int)(pixel / (uint32_t)sc.cam.width), (uint64_t)pixel * pass.spp + k, pass.seed, P, rad);
-                    if (!live) finish(sample, rad, 0u);   // (the single-shot estimators of version 1 and 2)
-                }
-                w_next += n_dead < left ? n_dead : left;
-            }
-        }
-        if (__ballot(live) == 0ull) { if (exhausted) break; else continue; }
-        if (live) {
-            f3 rad;
-            tr.tick(6);
-            if (!vol_path_step(sc, tr, P, rad)) { finish(sample, rad, P.bounce_iterations); live = false; }
-        }
-    }
-    const uint32_t wb = wave_sum(bounces);
-    if (lane == 0u && wb) atomicAdd((unsigned long long *)counters, (unsigned long long)wb);
-#if LJ_VOLPATH_STATS
-    for (int k = 0; k < 8; k++) {
-        const uint32_t e = wave_sum(tr.ev[k]), l = wave_sum(tr.ln[k]);
-        if (lane == 0u) { atomicAdd((unsigned long long *)counters + 2 + 2 * k, (unsigned long long)e); atomicAdd((unsigned long long *)counters + 3 + 2 * k, (unsigned long long)l); }
-    }
-#endif
-}
-// Two builds of the same body.  Unconstrained it takes ~250 VGPRs (two waves per SIMD); built for three waves (168, some spilled) the
-// scenes with homogeneous media run faster, but a heterogeneous medium — whose tracker keeps the grid-lookup state live through long
-// null-collision loops — slower.  The launcher picks by whether the scene holds a heterogeneous medium.
-__global__ void __launch_bounds__(kBlock) k_volpath(DScene sc, DPass pass, uint32_t n_samples, uint32_t grab, uint32_t *counters, int stack, int lds_nodes, int lds_prims, int *spill) {
-    volpath_body(sc, pass, n_samples, grab, counters, stack, lds_nodes, lds_prims, spill);
-}
-__global__ void __launch_bounds__(kBlock, 3) k_volpath3(DScene sc, DPass pass, uint32_t n_samples, uint32_t grab, uint32_t *counters, int stack, int lds_nodes, int lds_prims, int *spill) {
-    volpath_body(sc, pass, n_samples, grab, counters, stack, lds_nodes, lds_prims, spill);
-}
-__global__ void __launch_bounds__(kBlock, 4) k_volpath4(DScene sc, DPass pass, uint32_t n_samples, uint32_t grab, uint32_t *counters, int stack, int lds_nodes, int lds_prims, int *spill) {
-    volpath_body(sc, pass, n_samples, grab, counters, stack, lds_nodes, lds_prims, spill);
-}
-
 // ---------------------------------------------------------------- launchers (called from api_device.hip)
 // A traversal of a BVH4 with `depth` inner levels holds at most 3 * depth entries.  The first `stack` levels of every
 // lane's stack live in LDS (1 KiB per level and workgroup); deeper levels — rare — go to a global overflow buffer.
@@ -1000,24 +635,6 @@ void launch_resolve(const DPass &pass, uint32_t n_pixels, float *rgb, hipStream_
 }
 void launch_aux(const DScene &sc, const uint32_t *pixel_list, uint32_t n_pixels, int integrator, float *rgb, const ExtendConfig &cfg, int *spill, int grid, hipStream_t s) {
     if (n_pixels) hipLaunchKernelGGL(k_aux, dim3(grid), dim3(kBlock), cfg.smem, s, sc, pixel_list, n_pixels, integrator, rgb, cfg.stack, cfg.lds_nodes, cfg.lds_prims, spill);
-}
-void launch_volpath(const DScene &sc, const DPass &pass, uint32_t n_samples, uint32_t *counters, const ExtendConfig &cfg, int *spill, int grid, hipStream_t s) {
-    if (!n_samples) return;
-    int occ = sc.has_heterogeneous_medium != 0 ? 2 : 3;
-    if (const char *e = getenv("LJ_TUNE_VOLPATH_OCC")) occ = atoi(e);
-    // camera samples a wave takes off the counter at a time: every wave draws ~16 times, at least four samples per lane and at most 128 —
-    // a single address takes ~90 atomics per microsecond, which short paths (an absorbing medium: one step per sample) would otherwise feel
-    const uint64_t waves = (uint64_t)grid * (kBlock / 64);
-    uint32_t grab = (uint32_t)std::min<uint64_t>(8192, std::max<uint64_t>(256, (n_samples / (waves * 16)) & ~(uint64_t)63));
-    if (const char *e = getenv("LJ_TUNE_VOLPATH_GRAB")) grab = (uint32_t)(atoi(e) < 64 ? 64 : atoi(e)) & ~63u;
-    auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), cfg.smem, s, sc, pass, n_samples, grab, counters, cfg.stack, cfg.lds_nodes, cfg.lds_prims, spill); };
-    if (occ <= 2) launch(k_volpath); else if (occ == 3) launch(k_volpath3); else launch(k_volpath4);
-}
-int volpath_blocks_per_cu(const DScene &sc) {   // workgroups that stay resident per CU: the persistent grid is n_cus x this
-    if (const char *e = getenv("LJ_TUNE_VOLPATH_BLOCKS_PER_CU")) return atoi(e) > 0 ? atoi(e) : 1;
-    int occ = sc.has_heterogeneous_medium != 0 ? 2 : 3;
-    if (const char *e = getenv("LJ_TUNE_VOLPATH_OCC")) occ = atoi(e);
-    return occ < 2 ? 2 : (occ > 4 ? 4 : occ);
 }
 void launch_trace_rays(const DScene &sc, const void *rays, long long n, void *hits, unsigned char *occ, const ExtendConfig &cfg, int *spill, int grid, hipStream_t s) {
     if (cfg.wide) { launch_trace_rays8(sc, rays, n, hits, occ, cfg, spill, grid, s); return; }
