@@ -105,6 +105,42 @@ def test_bvh_traversal_equals_brute_force(name):
         assert np.array_equal(ho[f].view(np.uint32), hb[f].view(np.uint32)), f
 
 
+def _obj_scene(tmp_path, name, obj_text):
+    (tmp_path / (name + ".obj")).write_text(obj_text)
+    xml = tmp_path / (name + ".xml")
+    xml.write_text("""<scene version="0.6.0"><integrator type="path"><integer name="maxDepth" value="2"/></integrator>
+      <sensor type="perspective"><float name="fov" value="50"/><transform name="toWorld"><lookat origin="0.3, 0.4, 3" target="0, 0, 0" up="0, 1, 0"/></transform>
+        <sampler type="independent"><integer name="sampleCount" value="1"/></sampler>
+        <film type="hdrfilm"><integer name="width" value="32"/><integer name="height" value="32"/></film></sensor>
+      <shape type="obj"><string name="filename" value="%s.obj"/><bsdf type="diffuse"/><emitter type="area"><rgb name="radiance" value="1"/></emitter></shape></scene>""" % name)
+    return lj.parse_scene(str(xml))
+
+
+def test_bvh_builder_edge_cases_both_trees(tmp_path):
+    """What the two collapses of the builder (BVH4, and the BVH8 with quantised boxes) must survive: a single triangle (the root is a leaf),
+    many coincident triangles (no split separates them: the depth cap ends in leaves of up to 8, which the wide nodes take as two), an
+    axis-aligned flat scene (a grid step of zero extent), a long thin strip (one axis needs a far coarser grid than the others).  Closest
+    hits through either tree equal the oracle's exhaustive scan bit for bit."""
+    tri = "v -1 -1 0\nv 1 -1 0\nv 0 1 0\nf 1 2 3\n"
+    coincident = "v -1 -1 0\nv 1 -1 0\nv 0 1 0\n" + "f 1 2 3\n" * 37
+    flat = "".join("v %g %g 0\n" % (x, y) for y in range(5) for x in range(5)) + "".join(
+        "f %d %d %d\nf %d %d %d\n" % (y * 5 + x + 1, y * 5 + x + 2, (y + 1) * 5 + x + 2, y * 5 + x + 1, (y + 1) * 5 + x + 2, (y + 1) * 5 + x + 1) for y in range(4) for x in range(4))
+    strip = "".join("v %g 0 %g\nv %g 40 %g\n" % (i * 100.0, i * 1e-4, i * 100.0, i * 1e-4) for i in range(40)) + "".join(
+        "f %d %d %d\nf %d %d %d\n" % (2 * i + 1, 2 * i + 3, 2 * i + 2, 2 * i + 2, 2 * i + 3, 2 * i + 4) for i in range(39))
+    for name, text in (("tri", tri), ("coincident", coincident), ("flat", flat), ("strip", strip)):
+        hs = _obj_scene(tmp_path, name, text)
+        o, tw = Oracle(hs), Twin(hs)
+        o.use_bvh(False)
+        rays = random_rays(hs, 20000, 5, o)
+        ho, h4, h8 = o.intersect(rays), tw.intersect(rays), tw.intersect8(rays)
+        assert (ho["shape_id"] >= 0).any(), name
+        for f in ("t", "u", "v", "shape_id", "prim_id"):
+            assert np.array_equal(ho[f].view(np.uint32), h4[f].view(np.uint32)), (name, "bvh4", f)
+            assert np.array_equal(ho[f].view(np.uint32), h8[f].view(np.uint32)), (name, "bvh8", f)
+        info = tw.bvh8_info()
+        assert info["nodes"] >= 1 and info["leaf_slots"] >= 1
+
+
 def test_guided_cdf_search_is_the_full_search():
     """An environment map's two table searches (table_dist.cpp:116-139) run over a guide-table bracket on the device (dshade.h
     sample_cdf_guided); it must return the index of the full bisection for every u — random ones, every bin edge, every cdf value."""
