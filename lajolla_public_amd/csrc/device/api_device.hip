@@ -261,6 +261,14 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
     uint32_t seg = ((pool + n_blocks - 1) / n_blocks + 255u) & ~255u;
     const uint32_t n_slots = n_blocks * seg, lane_slots = lane_blocks * seg;
     ensure_queues(ctx, n_slots);
+    // feature sets that sort a segment as a whole shade from one set of queue records into another (kernels.hip shade_sorted_segment)
+    const bool sort_segments = ljd::shade_sorts_segments(sc->scfg);
+    if (sort_segments) {
+        const uint32_t cap = (n_slots + 63u) & ~63u;
+        if (ctx->queue2_capacity < cap) { ctx->queue_mem2.alloc(queue_bytes(cap)); ctx->queue2_capacity = cap; }
+        if (ctx->sort_perm.bytes < (size_t)cap * 4) ctx->sort_perm.alloc((size_t)cap * 4);
+        if (ctx->sort_keys.bytes < (size_t)cap) ctx->sort_keys.alloc((size_t)cap);
+    }
     // extend: persistent workgroups that draw 256-slot chunks of the queue.  One lane: more workgroups than fit at once, so
     // the hardware keeps every CU as full as registers and LDS allow; several lanes: few enough that the other lanes'
     // shade workgroups find registers beside them (8 extend waves per CU and lane).
@@ -282,8 +290,9 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
     if (!ctx->chunk_counter.p) ctx->chunk_counter.alloc(128 * kMaxLanes);
     if (ctx->chunk_list.bytes < (size_t)lane_chunks * 8 * n_lanes) ctx->chunk_list.alloc((size_t)lane_chunks * 8 * n_lanes);
     const ljd::DQueue q_all = carve_queue(ctx->queue_mem.p, ctx->queue_capacity);
+    const ljd::DQueue q2_all = sort_segments ? carve_queue(ctx->queue_mem2.p, ctx->queue2_capacity) : q_all;
     struct Lane {
-        hipStream_t stream; ljd::DQueue q; ljd::DBlockState *dblocks; ljd::DBlockState *hblocks;
+        hipStream_t stream; ljd::DQueue q, q2; uint32_t *sort_perm; uint8_t *sort_keys; ljd::DBlockState *dblocks; ljd::DBlockState *hblocks;
         uint32_t *work; uint32_t *lists[2]; uint32_t parity; int *spill; int *spill_tail; bool done; int batch;
     } lanes[kMaxLanes];
     for (uint32_t l = 0; l < n_lanes; l++) {
@@ -291,6 +300,8 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
         L.stream = l == 0 ? stream : ctx->lane_streams[l - 1];
         const size_t o = (size_t)l * lane_slots;
         L.q = q_all; L.q.ro += o; L.q.rd += o; L.q.rs += o; L.q.rh += o; L.q.rw += o; L.q.rl += o; L.q.rn += o; L.q.rg += o;
+        L.q2 = q2_all; L.q2.ro += o; L.q2.rd += o; L.q2.rs += o; L.q2.rh += o; L.q2.rw += o; L.q2.rl += o; L.q2.rn += o; L.q2.rg += o;
+        L.sort_perm = sort_segments ? (uint32_t *)ctx->sort_perm.p + o : nullptr; L.sort_keys = sort_segments ? (uint8_t *)ctx->sort_keys.p + o : nullptr;
         L.dblocks = (ljd::DBlockState *)ctx->blocks.p + (size_t)l * lane_blocks; L.hblocks = ctx->blocks_host + (size_t)l * lane_blocks;
         L.work = (uint32_t *)ctx->chunk_counter.p + 32 * l;
         L.lists[0] = (uint32_t *)ctx->chunk_list.p + (size_t)l * 2 * lane_chunks; L.lists[1] = L.lists[0] + lane_chunks;
@@ -330,7 +341,8 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
             // stagger: lane l starts when lane l-1 has generated its camera rays, so its shade launches fall on the other
             // lane's extend launches (the two lanes have equal work per step, so the phase offset persists)
             if (l > 0) HIP_CHECK(hipStreamWaitEvent(L.stream, ctx->ev_join, 0));
-            ljd::launch_shade(ds, pass, L.q, L.dblocks, lane_blocks, seg, sc->scfg, L.work, L.lists[0], 0, ext_grid * 4u, L.stream);
+            ljd::launch_shade(ds, pass, L.q, L.q2, L.sort_perm, L.sort_keys, L.dblocks, lane_blocks, seg, sc->scfg, L.work, L.lists[0], 0, ext_grid * 4u, L.stream);
+            if (sort_segments) std::swap(L.q, L.q2);   // (L.q: the set the paths are in now)
             if (l + 1 < n_lanes) HIP_CHECK(hipEventRecord(ctx->ev_join, L.stream));
         }
         // Round-robin over the lanes: look at a lane's block states only when its previous batch has drained, and give it
@@ -368,7 +380,8 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
                     ljd::launch_extend(ds, L.q, L.dblocks, ext_grid, seg, L.work, L.lists[L.parity], L.parity, sc->ecfg, L.spill, xstats, L.stream);
                     if (timing) HIP_CHECK(hipEventRecord(ctx->ev_k1, L.stream));
                     L.parity ^= 1u;
-                    ljd::launch_shade(ds, pass, L.q, L.dblocks, lane_blocks, seg, sc->scfg, L.work, L.lists[L.parity], L.parity, ext_grid * 4u, L.stream);
+                    ljd::launch_shade(ds, pass, L.q, L.q2, L.sort_perm, L.sort_keys, L.dblocks, lane_blocks, seg, sc->scfg, L.work, L.lists[L.parity], L.parity, ext_grid * 4u, L.stream);
+                    if (sort_segments) std::swap(L.q, L.q2);
                     if (timing) {
                         HIP_CHECK(hipEventRecord(ctx->ev_end, L.stream));
                         HIP_CHECK(hipEventSynchronize(ctx->ev_end));

@@ -20,7 +20,8 @@ int shade_variant(uint32_t kinds, bool textured, bool envmap, bool sphere_lights
 ExtendConfig extend_config(int n_nodes, int n_prims, int bvh_depth, int n_spheres, int n_nodes8, int bvh8_depth);
 int max_stack_depth();
 void launch_extend(const DScene &sc, const DQueue &q, const DBlockState *blocks, uint32_t grid, uint32_t seg, uint32_t *work, const uint32_t *chunk_list, uint32_t parity, const ExtendConfig &cfg, int *spill, unsigned long long *stats, hipStream_t s);
-void launch_shade(const DScene &sc, const DPass &pass, const DQueue &q, DBlockState *blocks, uint32_t n_blocks, uint32_t seg, const ShadeConfig &cfg, uint32_t *work, uint32_t *chunk_list, uint32_t parity, uint32_t extend_waves, hipStream_t s);
+bool shade_sorts_segments(const ShadeConfig &cfg);
+void launch_shade(const DScene &sc, const DPass &pass, const DQueue &q, const DQueue &qo, uint32_t *sort_perm, uint8_t *sort_keys, DBlockState *blocks, uint32_t n_blocks, uint32_t seg, const ShadeConfig &cfg, uint32_t *work, uint32_t *chunk_list, uint32_t parity, uint32_t extend_waves, hipStream_t s);
 void launch_resolve(const DPass &pass, uint32_t n_pixels, float *rgb, hipStream_t s);
 size_t tail_smem(const ExtendConfig &ecfg, const ShadeConfig &scfg);
 void launch_tail(const DScene &sc, const DPass &pass, const DQueue &q, DBlockState *blocks, uint32_t n_blocks, uint32_t seg, const ExtendConfig &ecfg, const ShadeConfig &scfg, int *spill, hipStream_t s);
@@ -68,6 +69,7 @@ struct lj_context {
     int n_cus = 256;
     // workspace, grown on demand and reused across renders
     DevBuf queue_mem; uint32_t queue_capacity = 0;
+    DevBuf queue_mem2, sort_perm, sort_keys; uint32_t queue2_capacity = 0;   // segment-sorted shading: the second record set, slot permutation, keys
     DevBuf chunk_counter, chunk_list;  // the extend kernel's work counters and the two lists of live queue chunks
     DevBuf spill;  // overflow levels of the traversal stacks: spill_levels x (grid * 256) ints
     DevBuf blocks, sample_rgb, pixel_list, frame;

@@ -267,6 +267,91 @@ __device__ __forceinline__ uint32_t shade_compact_segment(const DScene &sc, cons
     return out;
 }
 
+// The same with the WHOLE live front of the segment sorted by shade_key, not each 256-path chunk of it (k_shade, scenes with several
+// Material alternatives or an environment map).  Why: a chunk costs what its slowest wave costs — with the chunk's paths sorted that
+// is still the wave that got the heaviest class (disney_bsdf.xml: the Disney BSDF on 15 % of the paths), while the other three wait
+// at the chunk's barrier; sorted over the whole segment, most chunks hold ONE class and cost what that class costs.  Three passes over
+// the front: (1) keys (one byte per path, kept in `sb.keys`) and their histogram, (2) a stable scatter of the slot numbers into
+// `sb.perm` (key-major), (3) shading in that order — reading the queue records of slot perm[t] from `q` and writing the survivors,
+// compacted, to `qo`: a SECOND set of queue records, because a path read from anywhere in the segment may not be overwritten by an
+// earlier survivor.  The extend launch that follows works on `qo`; the two sets swap roles every step.
+struct ShadeSortBuf { uint32_t *perm; uint8_t *keys; };
+template <class Ft>
+__device__ __forceinline__ uint32_t shade_sorted_segment(const DScene &sc, const DPass &pass, const DQueue &q, const DQueue &qo, const ShadeSortBuf &sb, uint32_t base, uint32_t count,
+                                                         ShadeCounters &cnt, uint32_t (*s_wcnt)[kBlock / 64]) {
+    __shared__ uint32_t s_start[kShadeKeys];
+    __shared__ uint16_t s_kc[kShadeKeys][kBlock / 64];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    if (threadIdx.x < kShadeKeys) s_start[threadIdx.x] = 0u;
+    __syncthreads();
+    // ---- (1) keys and histogram
+    for (uint32_t c0 = 0; c0 < count; c0 += kBlock) {
+        const uint32_t j = c0 + threadIdx.x;
+        const int key = j < count ? shade_key<Ft>(sc, q, base + j) : kShadeKeys;
+        if (j < count) sb.keys[base + j] = (uint8_t)key;
+#pragma unroll
+        for (int k = 0; k < kShadeKeys; k++) {
+            if (k >= 3 && !Ft::kind(k - 3)) continue;
+            const unsigned long long m = __ballot(key == k);
+            if (lane == 0u && m != 0ull) atomicAdd(&s_start[k], (uint32_t)__popcll(m));
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t run = 0; for (int k = 0; k < kShadeKeys; k++) { const uint32_t c = s_start[k]; s_start[k] = run; run += c; } }
+    __syncthreads();
+    // ---- (2) slot numbers in (key, slot) order
+    for (uint32_t c0 = 0; c0 < count; c0 += kBlock) {
+        const uint32_t j = c0 + threadIdx.x;
+        const int key = j < count ? (int)sb.keys[base + j] : kShadeKeys;
+        uint32_t rank_in_key = 0;
+#pragma unroll
+        for (int k = 0; k < kShadeKeys; k++) {
+            if (k >= 3 && !Ft::kind(k - 3)) continue;
+            const unsigned long long m = __ballot(key == k);
+            if (key == k) rank_in_key = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (lane == 0u) s_kc[k][wave] = (uint16_t)__popcll(m);
+        }
+        __syncthreads();
+        if (key < kShadeKeys) {
+            uint32_t pos = s_start[key] + rank_in_key;
+            for (uint32_t w = 0; w < wave; w++) pos += s_kc[key][w];
+            sb.perm[base + pos] = j;
+        }
+        __syncthreads();
+        if (threadIdx.x < kShadeKeys) {
+            const int k = (int)threadIdx.x;
+            if (k < 3 || Ft::kind(k - 3)) { uint32_t n = 0; for (uint32_t w = 0; w < kBlock / 64; w++) n += s_kc[k][w]; s_start[k] += n; }
+        }
+        __syncthreads();
+    }
+    // ---- (3) shade in that order; survivors compacted into the other record set
+    uint32_t out = 0;
+    for (uint32_t c0 = 0, it = 0; c0 < count; c0 += kBlock, it++) {
+        const uint32_t t = c0 + threadIdx.x;
+        bool alive = false;
+        PathState ps;
+        if (t < count) {
+            const uint32_t j = sb.perm[base + t];
+            q_load_for_shade(q, base + j, ps);
+            alive = shade_path<Ft>(sc, pass, ps, cnt);
+            if (!alive) {
+                float *o = pass.sample_rgb + 3ull * ps.sample;
+                o[0] = ps.rad.x; o[1] = ps.rad.y; o[2] = ps.rad.z;
+                cnt.done++;
+            }
+        }
+        const unsigned long long mask = __ballot(alive);
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        if (lane == 0u) s_wcnt[it & 1][wave] = (uint32_t)__popcll(mask);
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+        for (uint32_t w = 0; w < kBlock / 64; w++) { const uint32_t n = s_wcnt[it & 1][w]; before += (w < wave) ? n : 0u; total += n; }
+        if (alive) q_store(qo, base + out + before + rank, ps);
+        out += total;
+    }
+    return out;
+}
+
 // (the feature sets the shade kernel is compiled for — FeatLambert ... FeatAll — are listed in dshade.h)
 #ifndef LJ_LAMBERT_OCC
 #define LJ_LAMBERT_OCC 4
@@ -283,7 +368,7 @@ template <> struct ShadeOccupancy<FeatLambertTex> { static constexpr int waves =
 template <> struct ShadeOccupancy<FeatDisney> { static constexpr int waves = LJ_SHADE_OCC_LARGE; };
 
 template <class Ft, int STAGE>
-__global__ void __launch_bounds__(kBlock, ShadeOccupancy<Ft>::waves) k_shade(DScene sc, DPass pass, DQueue q, DBlockState *blocks, uint32_t seg, ShadeStage stg, uint32_t *work, uint32_t *chunk_list, uint32_t parity, uint32_t extend_waves) {
+__global__ void __launch_bounds__(kBlock, ShadeOccupancy<Ft>::waves) k_shade(DScene sc, DPass pass, DQueue q, DQueue qo, ShadeSortBuf sb, DBlockState *blocks, uint32_t seg, ShadeStage stg, uint32_t *work, uint32_t *chunk_list, uint32_t parity, uint32_t extend_waves) {
     __shared__ uint32_t s_list_base;
     if (blockIdx.x == 0 && threadIdx.x == 0) work[0] = extend_waves;   // the extend launch that follows draws list entries beyond its own waves from it
     __shared__ uint32_t s_wcnt[2][kBlock / 64];
@@ -296,14 +381,17 @@ __global__ void __launch_bounds__(kBlock, ShadeOccupancy<Ft>::waves) k_shade(DSc
     ShadeCounters cnt; cnt.bounces = cnt.closest = cnt.shadow = cnt.done = 0;
     const uint32_t base = blockIdx.x * seg;
     // ---- shade the live front of the segment chunk by chunk; survivors are compacted to the front, in order
-    const uint32_t out = shade_compact_segment<Ft>(sc, pass, q, base, count, cnt, s_wcnt);
+    // (qo: the record set the survivors go to — `q` itself unless the segment is sorted as a whole, shade_sorted_segment)
+    uint32_t out;
+    if (ShadeSorted<Ft>::value && sb.perm != nullptr) out = shade_sorted_segment<Ft>(sc, pass, q, qo, sb, base, count, cnt, s_wcnt);
+    else out = shade_compact_segment<Ft>(sc, pass, q, base, count, cnt, s_wcnt);
     // ---- refill the rest of the segment with the workgroup's next camera samples (path_tracing.h:10-14)
     const uint32_t left = end_sample - next_sample, room = seg - out;
     const uint32_t n_new = left < room ? left : room;
     for (uint32_t g = threadIdx.x; g < n_new; g += kBlock) {
         PathState ps;
         generate_path(sc, pass, next_sample + g, ps);
-        q_store(q, base + out + g, ps);
+        q_store(qo, base + out + g, ps);
     }
     const uint32_t b = wave_sum(cnt.bounces), cl = wave_sum(cnt.closest), sh = wave_sum(cnt.shadow), dn = wave_sum(cnt.done);
     if ((threadIdx.x & 63) == 0) {
@@ -605,9 +693,17 @@ int shade_variant(uint32_t kinds, bool textured, bool envmap, bool sphere_lights
     return kNumShadeVariants - 1;
 }
 
-void launch_shade(const DScene &sc, const DPass &pass, const DQueue &q, DBlockState *blocks, uint32_t n_blocks, uint32_t seg, const ShadeConfig &cfg, uint32_t *work, uint32_t *chunk_list, uint32_t parity, uint32_t extend_waves, hipStream_t s) {
+bool shade_sorts_segments(const ShadeConfig &cfg) {   // feature sets whose k_shade sorts a segment as a whole (they need the second record set + sort buffers)
+    if (const char *e = getenv("LJ_TUNE_SHADE_SORT")) { if (atoi(e) < 2) return false; }
+    bool sorted = false;
+    if (cfg.smem == 0) return ShadeSorted<FeatAll>::value;
+    with_shade_variant(cfg.variant, [&](auto ft) { sorted = ShadeSorted<decltype(ft)>::value; });
+    return sorted;
+}
+void launch_shade(const DScene &sc, const DPass &pass, const DQueue &q, const DQueue &qo, uint32_t *sort_perm, uint8_t *sort_keys, DBlockState *blocks, uint32_t n_blocks, uint32_t seg, const ShadeConfig &cfg, uint32_t *work, uint32_t *chunk_list, uint32_t parity, uint32_t extend_waves, hipStream_t s) {
+    ShadeSortBuf sb; sb.perm = sort_perm; sb.keys = sort_keys;
     const ShadeStage st = make_shade_stage(cfg);
-    auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(n_blocks), dim3(kBlock), cfg.smem, s, sc, pass, q, blocks, seg, st, work, chunk_list, parity, extend_waves); };
+    auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(n_blocks), dim3(kBlock), cfg.smem, s, sc, pass, q, qo, sb, blocks, seg, st, work, chunk_list, parity, extend_waves); };
     // (a scene whose tables are not staged at all runs the all-features instantiation: lj_scene_upload picks it)
     const int stage = cfg.smem == 0 ? 0 : (cfg.stage_prims ? 2 : 1);
     if (stage == 0) { launch(k_shade<FeatAll, 0>); return; }
