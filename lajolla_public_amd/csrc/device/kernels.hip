@@ -186,6 +186,38 @@ __global__ void __launch_bounds__(kBlock, (RESIDENT && !SPHERES && !STATS) ? LJ_
 }
 
 // ---------------------------------------------------------------- shade + compaction
+struct ShadeSortBuf { uint32_t *perm; uint8_t *keys; uint32_t octant_bin; };   // (perm == nullptr: chunks are compacted in place)
+// Where a chunk's survivors go inside the output range [out, out + total): in thread order, or — `octant_bin` — grouped by the direction
+// octant of their new extension ray (a counting sort over eight keys by wave ballots), so that the 64 rays a wave of the extend kernel picks
+// up start out in the same octant.  Returns the survivor's offset and the chunk's total (identical in every thread).  Call from all threads.
+__device__ __forceinline__ uint32_t survivor_offset(bool alive, const PathState &ps, bool octant_bin, uint32_t (*s_cnt)[kBlock / 64], uint32_t &total) {
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    if (!octant_bin) {
+        const unsigned long long mask = __ballot(alive);
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        if (lane == 0u) s_cnt[0][wave] = (uint32_t)__popcll(mask);
+        __syncthreads();
+        uint32_t before = 0; total = 0;
+        for (uint32_t w = 0; w < kBlock / 64; w++) { const uint32_t n = s_cnt[0][w]; before += (w < wave) ? n : 0u; total += n; }
+        return before + rank;   // (the caller alternates between two count tables, so the next chunk's counts do not race these reads)
+    }
+    const uint32_t oct = (ps.dir.x < 0.0f ? 1u : 0u) | (ps.dir.y < 0.0f ? 2u : 0u) | (ps.dir.z < 0.0f ? 4u : 0u);
+    uint32_t rank = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 8u; k++) {
+        const unsigned long long m = __ballot(alive && oct == k);
+        if (alive && oct == k) rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (lane == 0u) s_cnt[k][wave] = (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    uint32_t before = 0; total = 0;
+    for (uint32_t k = 0; k < 8u; k++) for (uint32_t w = 0; w < kBlock / 64; w++) {
+        const uint32_t n = s_cnt[k][w];
+        before += (k < oct || (k == oct && w < wave)) ? n : 0u; total += n;
+    }
+    return before + rank;
+}
+
 // What a path will do in this shade step, as far as its queue records tell — the key its chunk is sorted by before shading (below):
 // 0 nothing (no extension ray was traced: only the pending next-event estimate is added), 1 its ray left the scene (environment map),
 // 2 it only accounts for the hit (Russian roulette ended it), 3 + k full shading on Material alternative k (material.h:102-110).
@@ -209,7 +241,7 @@ template <class Ft> struct ShadeSorted { static constexpr bool value = Ft::envma
 // table of counts and one of slots — so that a wave's lanes run the same branch of shade_path; the survivors are then compacted in that
 // order.  A path's value does not depend on where it sits in the queue (its radiance goes to sample_rgb[sample]), so images are unchanged.
 template <class Ft>
-__device__ __forceinline__ uint32_t shade_compact_segment(const DScene &sc, const DPass &pass, const DQueue &q, uint32_t base, uint32_t count, ShadeCounters &cnt, uint32_t (*s_wcnt)[kBlock / 64]) {
+__device__ __forceinline__ uint32_t shade_compact_segment(const DScene &sc, const DPass &pass, const DQueue &q, uint32_t base, uint32_t count, ShadeCounters &cnt, uint32_t (*s_oct)[kBlock / 64], bool octant_bin = false) {
     constexpr bool SORT = ShadeSorted<Ft>::value;
     __shared__ uint16_t s_perm[SORT ? kBlock : 1];
     __shared__ uint16_t s_kcnt[SORT ? kShadeKeys : 1][kBlock / 64];
@@ -253,15 +285,11 @@ __device__ __forceinline__ uint32_t shade_compact_segment(const DScene &sc, cons
                 cnt.done++;
             }
         }
-        const unsigned long long mask = __ballot(alive);
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-        if ((threadIdx.x & 63) == 0) s_wcnt[it & 1][wave] = (uint32_t)__popcll(mask);
-        // every record of this chunk has been read (and consumed) by now, so writing into [out, out + survivors) — which
-        // never reaches past the end of this chunk — cannot overtake a read
-        __syncthreads();
-        uint32_t before = 0, total = 0;
-        for (uint32_t w = 0; w < kBlock / 64; w++) { const uint32_t n = s_wcnt[it & 1][w]; before += (w < wave) ? n : 0u; total += n; }
-        if (alive) q_store(q, base + out + before + rank, ps);
+        // every record of this chunk has been read (and consumed) once the threads meet in survivor_offset, so writing into
+        // [out, out + survivors) — which never reaches past the end of this chunk — cannot overtake a read
+        uint32_t total;
+        const uint32_t off = survivor_offset(alive, ps, octant_bin, s_oct + (it & 1u) * 8u, total);
+        if (alive) q_store(q, base + out + off, ps);
         out += total;
     }
     return out;
@@ -275,10 +303,9 @@ __device__ __forceinline__ uint32_t shade_compact_segment(const DScene &sc, cons
 // `sb.perm` (key-major), (3) shading in that order — reading the queue records of slot perm[t] from `q` and writing the survivors,
 // compacted, to `qo`: a SECOND set of queue records, because a path read from anywhere in the segment may not be overwritten by an
 // earlier survivor.  The extend launch that follows works on `qo`; the two sets swap roles every step.
-struct ShadeSortBuf { uint32_t *perm; uint8_t *keys; };
 template <class Ft>
 __device__ __forceinline__ uint32_t shade_sorted_segment(const DScene &sc, const DPass &pass, const DQueue &q, const DQueue &qo, const ShadeSortBuf &sb, uint32_t base, uint32_t count,
-                                                         ShadeCounters &cnt, uint32_t (*s_wcnt)[kBlock / 64]) {
+                                                         ShadeCounters &cnt, uint32_t (*s_oct)[kBlock / 64]) {
     __shared__ uint32_t s_start[kShadeKeys];
     __shared__ uint16_t s_kc[kShadeKeys][kBlock / 64];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -340,13 +367,9 @@ __device__ __forceinline__ uint32_t shade_sorted_segment(const DScene &sc, const
                 cnt.done++;
             }
         }
-        const unsigned long long mask = __ballot(alive);
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-        if (lane == 0u) s_wcnt[it & 1][wave] = (uint32_t)__popcll(mask);
-        __syncthreads();
-        uint32_t before = 0, total = 0;
-        for (uint32_t w = 0; w < kBlock / 64; w++) { const uint32_t n = s_wcnt[it & 1][w]; before += (w < wave) ? n : 0u; total += n; }
-        if (alive) q_store(qo, base + out + before + rank, ps);
+        uint32_t total;
+        const uint32_t off = survivor_offset(alive, ps, sb.octant_bin != 0u, s_oct + (it & 1u) * 8u, total);
+        if (alive) q_store(qo, base + out + off, ps);
         out += total;
     }
     return out;
@@ -371,7 +394,7 @@ template <class Ft, int STAGE>
 __global__ void __launch_bounds__(kBlock, ShadeOccupancy<Ft>::waves) k_shade(DScene sc, DPass pass, DQueue q, DQueue qo, ShadeSortBuf sb, DBlockState *blocks, uint32_t seg, ShadeStage stg, uint32_t *work, uint32_t *chunk_list, uint32_t parity, uint32_t extend_waves) {
     __shared__ uint32_t s_list_base;
     if (blockIdx.x == 0 && threadIdx.x == 0) work[0] = extend_waves;   // the extend launch that follows draws list entries beyond its own waves from it
-    __shared__ uint32_t s_wcnt[2][kBlock / 64];
+    __shared__ uint32_t s_wcnt[16][kBlock / 64];   // two tables of (octant x wave) survivor counts, used alternately
     __shared__ unsigned long long s_cnt[5];
     stage_shade_tables<STAGE>(sc, stg, 0u);
     DBlockState &bs = blocks[blockIdx.x];
@@ -384,7 +407,7 @@ __global__ void __launch_bounds__(kBlock, ShadeOccupancy<Ft>::waves) k_shade(DSc
     // (qo: the record set the survivors go to — `q` itself unless the segment is sorted as a whole, shade_sorted_segment)
     uint32_t out;
     if (ShadeSorted<Ft>::value && sb.perm != nullptr) out = shade_sorted_segment<Ft>(sc, pass, q, qo, sb, base, count, cnt, s_wcnt);
-    else out = shade_compact_segment<Ft>(sc, pass, q, base, count, cnt, s_wcnt);
+    else out = shade_compact_segment<Ft>(sc, pass, q, base, count, cnt, s_wcnt, sb.octant_bin != 0u);
     // ---- refill the rest of the segment with the workgroup's next camera samples (path_tracing.h:10-14)
     const uint32_t left = end_sample - next_sample, room = seg - out;
     const uint32_t n_new = left < room ? left : room;
@@ -419,7 +442,7 @@ __global__ void __launch_bounds__(kBlock, ShadeOccupancy<Ft>::waves) k_shade(DSc
 template <class Ft>
 __global__ void __launch_bounds__(kBlock, 2) k_tail(DScene sc, DPass pass, DQueue q, DBlockState *blocks, uint32_t seg, ShadeStage stg, uint32_t shade_lds_at,
                                                     int stack, int lds_nodes, int lds_prims, int *spill) {
-    __shared__ uint32_t s_wcnt[2][kBlock / 64];
+    __shared__ uint32_t s_wcnt[16][kBlock / 64];   // two tables of (octant x wave) survivor counts, used alternately
     const TreeView tv = stage_tree(sc, stack, lds_nodes, lds_prims, spill, gridDim.x * kBlock, blockIdx.x * kBlock + threadIdx.x);
     DScene ssc = sc;                       // the shading view of the scene: tables in LDS
     stage_shade_tables<-1>(ssc, stg, shade_lds_at);
@@ -702,6 +725,7 @@ bool shade_sorts_segments(const ShadeConfig &cfg) {   // feature sets whose k_sh
 }
 void launch_shade(const DScene &sc, const DPass &pass, const DQueue &q, const DQueue &qo, uint32_t *sort_perm, uint8_t *sort_keys, DBlockState *blocks, uint32_t n_blocks, uint32_t seg, const ShadeConfig &cfg, uint32_t *work, uint32_t *chunk_list, uint32_t parity, uint32_t extend_waves, hipStream_t s) {
     ShadeSortBuf sb; sb.perm = sort_perm; sb.keys = sort_keys;
+    sb.octant_bin = (getenv("LJ_TUNE_OCTANT_BIN") && atoi(getenv("LJ_TUNE_OCTANT_BIN")) != 0) ? 1u : 0u;
     const ShadeStage st = make_shade_stage(cfg);
     auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(n_blocks), dim3(kBlock), cfg.smem, s, sc, pass, q, qo, sb, blocks, seg, st, work, chunk_list, parity, extend_waves); };
     // (a scene whose tables are not staged at all runs the all-features instantiation: lj_scene_upload picks it)
