@@ -519,7 +519,7 @@ int lj_scene_upload(lj_context *ctx, const LjSceneDesc *desc, lj_scene **out) {
         }
         if (F.bvh_depth > ljd::max_stack_depth())
             throw LjError(LJ_ERR_INTERNAL, "BVH depth " + std::to_string(F.bvh_depth) + " exceeds the traversal stack");
-        sc->ecfg = ljd::extend_config((int)F.nodes.size(), (int)F.leaf_prims.size(), F.bvh_depth, (int)F.n_spheres, (int)F.nodes8.size(), F.bvh8_depth);
+        sc->ecfg = ljd::extend_config((int)F.nodes.size(), (int)F.leaf_prims.size(), F.bvh_depth, (int)F.n_spheres, (int)F.nodes8.size(), F.bvh8_depth, /* open scene: */ F.envmap_light_id >= 0);
         if (const char *e = getenv("LJ_TUNE_REFILL")) sc->ecfg.refill_min = (uint32_t)atoi(e);
         if (const char *e = getenv("LJ_TUNE_MINDESC")) sc->ecfg.min_descending = (uint32_t)atoi(e);
         sc->scfg = ljd::shade_config(F.prims.size(), F.materials.size(), F.lights.size(), F.light_tris.size(), F.light_tri_cdf.size(), F.images3.size(), F.images1.size(), (size_t)F.env_marg_count);
@@ -604,12 +604,16 @@ static int trace_batch(lj_scene *scene, int64_t n, const LjRay *rays_host, LjHit
         // a tiny scene is traced by the leaf scan of mega.hip in a render, so that is what answers here too (LJ_TUNE_MEGA=0: the BVH
         // traversal of k_extend, as for every other scene)
         const bool scan = scene->dscene.n_scan_leaves > 0 && !(getenv("LJ_TUNE_MEGA") && atoi(getenv("LJ_TUNE_MEGA")) == 0);
+        HIP_CHECK(hipEventRecord(ctx->ev_begin, ctx->stream));
         if (scan) ljd::launch_trace_rays_scan(scene->dscene, rays.p, n, hits_host ? out.p : nullptr, hits_host ? nullptr : (unsigned char *)out.p, grid, ctx->stream);
         else ljd::launch_trace_rays(scene->dscene, rays.p, n, hits_host ? out.p : nullptr, hits_host ? nullptr : (unsigned char *)out.p, scene->ecfg, ensure_spill(ctx, scene->ecfg.spill_levels, (uint32_t)grid), grid, ctx->stream);
         HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipEventRecord(ctx->ev_end, ctx->stream));
         if (hits_host) HIP_CHECK(hipMemcpyAsync(hits_host, out.p, (size_t)n * sizeof(LjHit), hipMemcpyDeviceToHost, ctx->stream));
         else HIP_CHECK(hipMemcpyAsync(occ_host, out.p, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
+        scene->stats = LjStats{}; scene->stats.render_ms = ms; scene->stats.rays_closest = hits_host ? (uint64_t)n : 0; scene->stats.rays_shadow = hits_host ? 0 : (uint64_t)n;   // (the query kernel's device time)
     });
 }
 int lj_intersect(lj_scene *scene, int64_t n, const LjRay *rays_host, LjHit *hits_host) {

@@ -17,7 +17,7 @@
 namespace ljd {
 ShadeConfig shade_config(size_t n_prims, size_t n_materials, size_t n_lights, size_t n_light_tris, size_t n_light_tri_cdf, size_t n_images3, size_t n_images1, size_t n_env_marg);
 int shade_variant(uint32_t kinds, bool textured, bool envmap, bool sphere_lights);
-ExtendConfig extend_config(int n_nodes, int n_prims, int bvh_depth, int n_spheres, int n_nodes8, int bvh8_depth);
+ExtendConfig extend_config(int n_nodes, int n_prims, int bvh_depth, int n_spheres, int n_nodes8, int bvh8_depth, bool open_scene);
 int max_stack_depth();
 void launch_extend(const DScene &sc, const DQueue &q, const DBlockState *blocks, uint32_t grid, uint32_t seg, uint32_t *work, const uint32_t *chunk_list, uint32_t parity, const ExtendConfig &cfg, int *spill, unsigned long long *stats, hipStream_t s);
 bool shade_sorts_segments(const ShadeConfig &cfg);

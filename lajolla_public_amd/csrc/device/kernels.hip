@@ -609,7 +609,7 @@ __global__ void __launch_bounds__(kBlock) k_aux(DScene sc, const uint32_t *pixel
 // LDS per 256-thread workgroup = stack * 1 KiB + staged nodes * 112 B + staged prims * 48 B; four workgroups share a
 // CU's 160 KiB, so the budget per workgroup is 40 KiB.
 
-ExtendConfig extend_config(int n_nodes, int n_prims, int bvh_depth, int n_spheres, int n_nodes8, int bvh8_depth) {
+ExtendConfig extend_config(int n_nodes, int n_prims, int bvh_depth, int n_spheres, int n_nodes8, int bvh8_depth, bool open_scene) {
     ExtendConfig c{};
     c.spheres = n_spheres > 0 ? 1 : 0;
     const int need = 3 * (bvh_depth < 1 ? 1 : bvh_depth);
@@ -641,14 +641,19 @@ ExtendConfig extend_config(int n_nodes, int n_prims, int bvh_depth, int n_sphere
     // A tree beyond the LDS image can be traversed as a BVH8 instead (k_extend8, extend8.hip): 8-byte group entries, at most one push per
     // step, 80-byte nodes.  Measured on MI355X (tools/bvh8_ab.sh, tools/ab1024.sh, profiles/r03_bvh8_ab.txt): 26 % fewer node steps per ray
     // and a third fewer vector-memory instructions, but 26 % more VALU instructions (eight quantised children cost ~200 per step), and with
-    // five waves per SIMD the extend kernel is bound by instruction issue, not by the gather path — sponza 1024 spp 815 ms against 784 with
-    // the BVH4 kernel, disney_bsdf 256 spp 88.5 against 90.6.  So the BVH4 kernel stays the default and LJ_TUNE_BVH8=1 selects this one.
+    // five waves per SIMD the extend kernel is bound by instruction issue, not by the gather path.  Which tree wins depends on what the rays
+    // do.  In a closed scene every ray ends on a surface and the BVH4's distance-sorted descent culls most of what lies behind it: sponza
+    // 1024 spp 784 ms (BVH4) against 815.  In an open scene under an environment map most rays leave the scene — a ray that hits nothing
+    // visits everything along its way whatever the order, so the BVH8's fewer steps are all gain: disney_bsdf 256 spp 82.5 ms against 85.3,
+    // matpreview 64 spp 61.0 against 65.3, disney_metal 25.3 against 26.4.  So: BVH8 for trees beyond the LDS image of scenes lit by an
+    // environment map, BVH4 otherwise; LJ_TUNE_BVH8=0 / 1 overrides.
     // A ray's stack is rarely more than four groups deep (sponza: 1 push in 600 lands on level 4, 1 in 10^5 on level 6), so six levels
     // live in LDS and the rest of the tree's depth goes to the global overflow buffer; with the first 96 nodes (three full levels and part
     // of the fourth) and the pools a workgroup takes 29.5 KiB: five per CU.  `spill_levels` counts 4-byte units per lane (ensure_spill):
     // two per group level.
-    c.wide = 0;
-    if (const char *e = getenv("LJ_TUNE_BVH8")) c.wide = (atoi(e) != 0 && !c.resident && n_nodes > c.lds_nodes && n_nodes8 > 0) ? 1 : 0;
+    const bool can_wide = !c.resident && n_nodes > c.lds_nodes && n_nodes8 > 0;
+    c.wide = (can_wide && open_scene) ? 1 : 0;
+    if (const char *e = getenv("LJ_TUNE_BVH8")) c.wide = (atoi(e) != 0 && can_wide) ? 1 : 0;
     if (c.wide) {
         int cap8 = 6, nodes8 = 96;
         if (const char *e = getenv("LJ_TUNE_EXT8_STACK")) cap8 = atoi(e);

@@ -21,8 +21,9 @@ def ctx():
 def test_bvh8_kernels_match_oracle_and_bvh4(name, ctx, monkeypatch):
     hs = lj.parse_scene(scene_path(name))
     o = Oracle(hs)
+    monkeypatch.setenv("LJ_TUNE_BVH8", "0")   # read at upload (the default is by scene: BVH8 under an environment map, BVH4 otherwise)
     sc4 = lj.Scene(ctx, hs)
-    monkeypatch.setenv("LJ_TUNE_BVH8", "1")   # read at upload: this scene object walks the DNode8 tree
+    monkeypatch.setenv("LJ_TUNE_BVH8", "1")   # this scene object walks the DNode8 tree
     sc8 = lj.Scene(ctx, hs)
     monkeypatch.delenv("LJ_TUNE_BVH8")
     rays = random_rays(hs, 1 << 19, 21, o)
