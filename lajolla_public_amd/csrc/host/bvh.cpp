@@ -208,6 +208,78 @@ struct Builder {
 // ---- the binary tree collapsed eight wide, children quantised on a per-node grid (device/dtypes.h DNode8)
 namespace {
 
+// Which binary nodes become the children of a wide node.  `kids_of(n, W)` with W = 8 or 4: the children of the wide node rooted at binary
+// inner node n.  Two rules:
+//  greedy (default): start from n's two children and keep opening the inner child with the largest surface area;
+//  optimal (LJ_TUNE_COLLAPSE=1; Ylitie, Karras, Laine 2017, section 4.1, for fixed leaves): a dynamic programme over the binary tree that minimises the
+//  summed surface area of all wide nodes — the expected number of node visits of a random ray — cost[n][i] being the cheapest way to cover
+//  n's subtree with at most i roots (wide nodes or leaves) that hang under one parent:
+//      cost[leaf][i] = 0                                   (leaves are the same in every collapse)
+//      cost[n][1]    = area(n) + split[n][W]               (n is a wide node)
+//      cost[n][i]    = min(split[n][i], cost[n][i - 1])    with split[n][j] = min over k of cost[left][k] + cost[right][j - k]
+//  Measured (round 3): on the host twin's path rays the optimal collapse saves 6 % of an extension ray's BVH8 node steps and 3 % of its BVH4
+//  steps (sponza 12.27 -> 11.56 / 16.98 -> 16.47; 13 % fewer nodes), on the GPU nothing (sponza 256 spp 197.9 vs 195.1 ms, disney_bsdf 83.1 vs
+//  82.6, matpreview 60.1 vs 61.2): the extend kernels are not bound by their step count.  So the greedy rule stays.
+struct Collapse {
+    const std::vector<TmpNode> &tmp;
+    int W; bool optimal;
+    std::vector<float> cost;            // [node][i - 1], i = 1 .. W
+    std::vector<unsigned char> how;     // [node][i - 1]: 0 = as cost[n][i - 1]; k >= 1 = left gets k roots, right i - k; for i == 1: unused
+    Collapse(const std::vector<TmpNode> &t, int width, int root) : tmp(t), W(width) {
+        optimal = getenv("LJ_TUNE_COLLAPSE") && atoi(getenv("LJ_TUNE_COLLAPSE")) != 0;
+        if (!optimal) return;
+        cost.assign(tmp.size() * (size_t)W, 0.0f); how.assign(tmp.size() * (size_t)W, 0);
+        // post-order without recursion (the tree can be 40 levels deep, but wide scenes have millions of nodes)
+        std::vector<int> order, stack{root};
+        while (!stack.empty()) { const int n = stack.back(); stack.pop_back(); order.push_back(n); if (tmp[n].left >= 0) { stack.push_back(tmp[n].left); stack.push_back(tmp[n].right); } }
+        for (size_t q = order.size(); q-- > 0;) {
+            const int n = order[q];
+            if (tmp[n].left < 0) continue;   // leaf: all zero
+            const float *cl = &cost[(size_t)tmp[n].left * W], *cr = &cost[(size_t)tmp[n].right * W];
+            float split[9]; unsigned char arg[9];
+            for (int j = 2; j <= W; j++) {
+                float best = std::numeric_limits<float>::infinity(); int bk = 1;
+                for (int k = 1; k < j; k++) { const float c = cl[k - 1] + cr[j - k - 1]; if (c < best) { best = c; bk = k; } }
+                split[j] = best; arg[j] = (unsigned char)bk;
+            }
+            float *c = &cost[(size_t)n * W]; unsigned char *h = &how[(size_t)n * W];
+            c[0] = tmp[n].box.half_area() + split[W]; h[0] = 0;
+            for (int i = 2; i <= W; i++) {
+                if (split[i] < c[i - 2]) { c[i - 1] = split[i]; h[i - 1] = arg[i]; }
+                else { c[i - 1] = c[i - 2]; h[i - 1] = 0; }
+            }
+        }
+    }
+    void expand(int n, int i, std::vector<int> &out) const {   // the roots that cover n's subtree within a budget of i
+        if (tmp[n].left < 0 || i == 1) { out.push_back(n); return; }
+        const unsigned char k = how[(size_t)n * W + i - 1];
+        if (k == 0) { expand(n, i - 1, out); return; }
+        expand(tmp[n].left, k, out); expand(tmp[n].right, i - k, out);
+    }
+    void kids_of(int n, int *kids, int &count) const {
+        if (optimal) {
+            // the wide node rooted at n distributes its W slots over its two subtrees as split[n][W] decided: that is how[n][W - 1] unless
+            // cost[n][W] fell back to fewer roots — the split for the node's OWN children is recomputed here from the children's tables
+            const float *cl = &cost[(size_t)tmp[n].left * W], *cr = &cost[(size_t)tmp[n].right * W];
+            float best = std::numeric_limits<float>::infinity(); int bk = 1;
+            for (int k = 1; k < W; k++) { const float c = cl[k - 1] + cr[W - k - 1]; if (c < best) { best = c; bk = k; } }
+            std::vector<int> out;
+            expand(tmp[n].left, bk, out); expand(tmp[n].right, W - bk, out);
+            count = (int)out.size();
+            for (int k = 0; k < count; k++) kids[k] = out[k];
+            return;
+        }
+        kids[0] = tmp[n].left; kids[1] = tmp[n].right; count = 2;
+        while (count < W) {
+            int pick = -1; float area = -1.0f;
+            for (int k = 0; k < count; k++) if (tmp[kids[k]].left >= 0) { const float a = tmp[kids[k]].box.half_area(); if (a > area) { area = a; pick = k; } }
+            if (pick < 0) break;
+            const TmpNode &c = tmp[kids[pick]];
+            kids[pick] = c.left; kids[count++] = c.right;
+        }
+    }
+};
+
 // grid step exponent for one axis: the smallest e with 255 * 2^e >= extent (so every plane of the node fits 8 bits)
 int grid_exponent(double extent) {
     int e = -126;
@@ -272,19 +344,12 @@ void build_bvh(const std::vector<BuildPrim> &prims, int max_leaf, int max_depth,
         struct Wide8 { int kids[8]; int n; int depth; };
         std::vector<int> queue{root}, qdepth{1};
         const bool root_leaf = is_leaf(root);
+        const Collapse collapse8(b.tmp, 8, root);
         for (size_t h = 0; h < queue.size(); h++) {
             Wide8 w; w.depth = qdepth[h];
             if (root_leaf) { w.kids[0] = root; w.n = 1; }
             else {
-                const TmpNode &t = b.tmp[queue[h]];
-                w.kids[0] = t.left; w.kids[1] = t.right; w.n = 2;
-                while (w.n < 8) {   // open the inner child with the largest surface area
-                    int pick = -1; float area = -1.0f;
-                    for (int k = 0; k < w.n; k++) if (!is_leaf(w.kids[k])) { const float a = b.tmp[w.kids[k]].box.half_area(); if (a > area) { area = a; pick = k; } }
-                    if (pick < 0) break;
-                    const TmpNode &c = b.tmp[w.kids[pick]];
-                    w.kids[pick] = c.left; w.kids[w.n++] = c.right;
-                }
+                collapse8.kids_of(queue[h], w.kids, w.n);
             }
             depth8_out = std::max(depth8_out, w.depth);
             // grid: origin = lower corner of the union, one power-of-two step per axis
@@ -367,16 +432,10 @@ void build_bvh(const std::vector<BuildPrim> &prims, int max_leaf, int max_depth,
     std::vector<int> queue{root};
     wide_of[root] = 0;
     std::vector<int> qdepth{1};
+    const Collapse collapse4(b.tmp, 4, root);
     for (size_t h = 0; h < queue.size(); h++) {
-        const TmpNode &t = b.tmp[queue[h]];
-        Wide w; w.kids[0] = t.left; w.kids[1] = t.right; w.n = 2; w.depth = qdepth[h];
-        while (w.n < 4) {
-            int pick = -1; float area = -1.0f;
-            for (int k = 0; k < w.n; k++) if (!is_leaf(w.kids[k])) { const float a = b.tmp[w.kids[k]].box.half_area(); if (a > area) { area = a; pick = k; } }
-            if (pick < 0) break;
-            const TmpNode &c = b.tmp[w.kids[pick]];
-            w.kids[pick] = c.left; w.kids[w.n++] = c.right;
-        }
+        Wide w; w.depth = qdepth[h];
+        collapse4.kids_of(queue[h], w.kids, w.n);
         for (int k = 0; k < w.n; k++) if (!is_leaf(w.kids[k])) { wide_of[w.kids[k]] = (int)queue.size(); queue.push_back(w.kids[k]); qdepth.push_back(w.depth + 1); }
         wide.push_back(w);
         depth_out = std::max(depth_out, w.depth);
