@@ -8,11 +8,10 @@
 
 namespace ljd {
 
-// ---------------------------------------------------------------- volumetric path tracer (dvol.h)
-// One lane walks one camera sample's whole path; closest hits come from the same traversal steps the extend kernel uses.
+// ---------------------------------------------------------------- the tracer's ray casts: lane by lane through the BVH4
 // LJ_VOLPATH_STATS (a developer build, tools/dev/volpath_stats.sh): wave-level counts of how often each part of the volumetric tracer
 // runs and how many lanes are active in it — slots: 0 traversal node iterations, 1 leaf steps, 2 closest() calls, 3 / 4 tracking iterations
-// of the bounce loop / of shadow segments, 5 shadow segments, 6 vol_path_step calls.  counters[4 + 2 s], [5 + 2 s] (64 bit): events, lanes.
+// of the bounce loop / of shadow segments, 5 shadow segments, 6 vol_path_step calls.  64-bit words 2 + 2 s and 3 + 2 s of `counters`: wave-level events, lane-events.
 #ifndef LJ_VOLPATH_STATS
 #define LJ_VOLPATH_STATS 0
 #endif
