@@ -15,6 +15,8 @@ namespace ljd {
 #ifndef LJ_VOLPATH_STATS
 #define LJ_VOLPATH_STATS 0
 #endif
+// SPHERES: the scene holds sphere shapes (their test is the reference's double-precision callback: a scene without any does not carry it)
+template <bool SPHERES>
 struct DevTracer {
     const TreeView &tv;
 #if LJ_VOLPATH_STATS
@@ -34,7 +36,7 @@ struct DevTracer {
         tick(2);
         while (L.cur != kDone) {
             while (L.cur >= 0 && L.cur != kDone) { tick(0); trav_node_step<false>(tv, L); }
-            if (L.cur < 0) { tick(1); trav_leaf_step<false, true>(tv, L, false); }
+            if (L.cur < 0) { tick(1); trav_leaf_step<false, SPHERES>(tv, L, false); }
         }
         trav_finish(L);
         if (L.best.gprim < 0) return false;
@@ -48,10 +50,10 @@ struct DevTracer {
 // up takes the next `grab` samples off one grid-wide counter — so the lanes of a wave stay busy whatever the lengths of their paths
 // (one whole path per lane left a wave waiting for its longest path).  A sample's value depends on its pcg32 stream only.
 // counters[0..1]: bounce iterations (64 bit); counters[2]: the sample counter (zeroed before the launch).
-template <class Ft>
+template <class Ft, bool SPHERES>
 __device__ __forceinline__ void volpath_body(const DScene &sc, const DPass &pass, uint32_t n_samples, uint32_t grab, uint32_t *counters, int stack, int lds_nodes, int lds_prims, int *spill) {
     const TreeView tv = stage_tree(sc, stack, lds_nodes, lds_prims, spill, gridDim.x * kBlock, blockIdx.x * kBlock + threadIdx.x);
-    DevTracer tr{tv};
+    DevTracer<SPHERES> tr{tv};
 #if LJ_VOLPATH_STATS
     for (int k = 0; k < 8; k++) { tr.ev[k] = 0; tr.ln[k] = 0; }
 #endif
@@ -110,9 +112,9 @@ __device__ __forceinline__ void volpath_body(const DScene &sc, const DPass &pass
 }
 // Instantiated per feature set of the scene (dshade.h: a scene of diffuse surfaces does not carry nine BSDFs), built for three waves per SIMD.
 // (The tracker's own state, not the BSDFs, is what fills the registers: 211 VGPRs unconstrained for diffuse-only against 224 for everything.)
-template <class Ft, int OCC>
+template <class Ft, int OCC, bool SPHERES>
 __global__ void __launch_bounds__(kBlock, OCC) k_volpath(DScene sc, DPass pass, uint32_t n_samples, uint32_t grab, uint32_t *counters, int stack, int lds_nodes, int lds_prims, int *spill) {
-    volpath_body<Ft>(sc, pass, n_samples, grab, counters, stack, lds_nodes, lds_prims, spill);
+    volpath_body<Ft, SPHERES>(sc, pass, n_samples, grab, counters, stack, lds_nodes, lds_prims, spill);
 }
 
 // ---------------------------------------------------------------- launcher
@@ -131,9 +133,11 @@ void launch_volpath(const DScene &sc, const DPass &pass, uint32_t n_samples, uin
     auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), cfg.smem, s, sc, pass, n_samples, grab, counters, cfg.stack, cfg.lds_nodes, cfg.lds_prims, spill); };
     // feature sets compiled for this kernel: diffuse only / the three classic materials / everything (the smallest that covers the scene's)
     const int v = shade_variant <= 0 ? 0 : (shade_variant <= 2 ? 2 : kShadeVariantAll);
-    if (v == 0) launch(k_volpath<FeatLambert, 3>);
-    else if (v == 2) launch(k_volpath<FeatClassic, 3>);
-    else { if (occ <= 2) launch(k_volpath<FeatAll, 2>); else launch(k_volpath<FeatAll, 3>); }
+    const bool sph = cfg.spheres != 0;
+    if (v == 0) { if (sph) launch(k_volpath<FeatLambert, 3, true>); else launch(k_volpath<FeatLambert, 3, false>); }
+    else if (v == 2) { if (sph) launch(k_volpath<FeatClassic, 3, true>); else launch(k_volpath<FeatClassic, 3, false>); }
+    else if (occ <= 2) launch(k_volpath<FeatAll, 2, true>);
+    else { if (sph) launch(k_volpath<FeatAll, 3, true>); else launch(k_volpath<FeatAll, 3, false>); }
 }
 int volpath_blocks_per_cu(const DScene &sc) {   // workgroups that stay resident per CU: the persistent grid is n_cus x this
     if (const char *e = getenv("LJ_TUNE_VOLPATH_BLOCKS_PER_CU")) return atoi(e) > 0 ? atoi(e) : 1;
