@@ -73,7 +73,7 @@ struct DPrimShade {
 };
 static_assert(sizeof(DPrimShade) == 112, "DPrimShade layout");
 
-struct DSphere { double center[3]; double radius; };
+struct DSphere { double center[3]; double radius; int32_t gprim, _pad; };   // gprim: the sphere's global primitive id
 
 // One leaf of a tiny scene's flat leaf table (dscan.h): padded box + its primitives [first, first + count) of the leaf-ordered
 // primitive array.  32 bytes: one s_load_dwordx8.
@@ -146,6 +146,7 @@ struct DScene {
     const DPrim *leaf_prims; int32_t n_prims;
     const DPrimShade *prims;
     const DSphere *spheres;          // indexed by sphere_slot
+    int32_t n_spheres;
     const DMaterial *materials; int32_t n_materials;
     const DLight *lights; int32_t n_lights;
     const float *light_cdf;          // n_lights + 1

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <algorithm>
+#include <type_traits>
 #include "dtrav.h"
 #include "dvol.h"
 
@@ -15,10 +16,15 @@ namespace ljd {
 #ifndef LJ_VOLPATH_STATS
 #define LJ_VOLPATH_STATS 0
 #endif
-// SPHERES: the scene holds sphere shapes (their test is the reference's double-precision callback: a scene without any does not carry it)
-template <bool SPHERES>
+// SPHERES: 0 the scene holds no sphere; 1 spheres are tested where the traversal meets their leaves; 2 (a scene with a single sphere)
+// the traversal passes over them — a sphere's leaf-ordered record has three zero vertices, which the triangle test rejects — and every
+// ray tests every sphere afterwards.  Why: inlined into the lane-by-lane leaf step, the reference's double-precision sphere callback holds
+// ~50 VGPRs at the tracer's register peak (65 - 112 spilled registers instead of 8 - 63); after the traversal its registers are free.
+// The closest hit is the minimum of (t, primitive id) over everything tested, so where a test happens cannot change it.
+template <int SPHERES>
 struct DevTracer {
     const TreeView &tv;
+    const DSphere *spheres; int n_spheres;
 #if LJ_VOLPATH_STATS
     uint32_t ev[8], ln[8];   // ln: events this lane was active in; ev: events this lane was the first active lane of (their sum over a wave = the wave's events)
     __device__ __forceinline__ void tick(int s) {
@@ -36,12 +42,21 @@ struct DevTracer {
         tick(2);
         while (L.cur != kDone) {
             while (L.cur >= 0 && L.cur != kDone) { tick(0); trav_node_step<false>(tv, L); }
-            if (L.cur < 0) { tick(1); trav_leaf_step<false, SPHERES>(tv, L, false); }
+            if (L.cur < 0) { tick(1); trav_leaf_step<false, SPHERES == 1>(tv, L, false); }
         }
         trav_finish(L);
-        if (L.best.gprim < 0) return false;
         t = L.best.t; u = L.best.u; v = L.best.v; gprim = L.best.gprim;
-        return true;
+        if (SPHERES == 2) {
+            RayF ray; ray.ox = org.x; ray.oy = org.y; ray.oz = org.z; ray.dx = dir.x; ray.dy = dir.y; ray.dz = dir.z; ray.tnear = tnear; ray.tfar = tfar;
+            for (int s = 0; s < n_spheres; s++) {
+                double td;
+                if (sphere_test(ray, spheres[s], td)) {
+                    const float tf = (float)td; const int g = spheres[s].gprim;
+                    if (tf < t || (tf == t && (gprim < 0 || g < gprim))) { t = tf; u = 0.0f; v = 0.0f; gprim = g; }   // the rule of trav_leaf_step on (t, gprim)
+                }
+            }
+        }
+        return gprim >= 0;
     }
 };
 
@@ -50,10 +65,10 @@ struct DevTracer {
 // up takes the next `grab` samples off one grid-wide counter — so the lanes of a wave stay busy whatever the lengths of their paths
 // (one whole path per lane left a wave waiting for its longest path).  A sample's value depends on its pcg32 stream only.
 // counters[0..1]: bounce iterations (64 bit); counters[2]: the sample counter (zeroed before the launch).
-template <class Ft, bool SPHERES>
+template <class Ft, int SPHERES>
 __device__ __forceinline__ void volpath_body(const DScene &sc, const DPass &pass, uint32_t n_samples, uint32_t grab, uint32_t *counters, int stack, int lds_nodes, int lds_prims, int *spill) {
     const TreeView tv = stage_tree(sc, stack, lds_nodes, lds_prims, spill, gridDim.x * kBlock, blockIdx.x * kBlock + threadIdx.x);
-    DevTracer<SPHERES> tr{tv};
+    DevTracer<SPHERES> tr{tv, sc.spheres, sc.n_spheres};
 #if LJ_VOLPATH_STATS
     for (int k = 0; k < 8; k++) { tr.ev[k] = 0; tr.ln[k] = 0; }
 #endif
@@ -112,7 +127,7 @@ __device__ __forceinline__ void volpath_body(const DScene &sc, const DPass &pass
 }
 // Instantiated per feature set of the scene (dshade.h: a scene of diffuse surfaces does not carry nine BSDFs), built for three waves per SIMD.
 // (The tracker's own state, not the BSDFs, is what fills the registers: 211 VGPRs unconstrained for diffuse-only against 224 for everything.)
-template <class Ft, int OCC, bool SPHERES>
+template <class Ft, int OCC, int SPHERES>
 __global__ void __launch_bounds__(kBlock, OCC) k_volpath(DScene sc, DPass pass, uint32_t n_samples, uint32_t grab, uint32_t *counters, int stack, int lds_nodes, int lds_prims, int *spill) {
     volpath_body<Ft, SPHERES>(sc, pass, n_samples, grab, counters, stack, lds_nodes, lds_prims, spill);
 }
@@ -133,11 +148,17 @@ void launch_volpath(const DScene &sc, const DPass &pass, uint32_t n_samples, uin
     auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), cfg.smem, s, sc, pass, n_samples, grab, counters, cfg.stack, cfg.lds_nodes, cfg.lds_prims, spill); };
     // feature sets compiled for this kernel: diffuse only / the three classic materials / everything (the smallest that covers the scene's)
     const int v = shade_variant <= 0 ? 0 : (shade_variant <= 2 ? 2 : kShadeVariantAll);
-    const bool sph = cfg.spheres != 0;
-    if (v == 0) { if (sph) launch(k_volpath<FeatLambert, 3, true>); else launch(k_volpath<FeatLambert, 3, false>); }
-    else if (v == 2) { if (sph) launch(k_volpath<FeatClassic, 3, true>); else launch(k_volpath<FeatClassic, 3, false>); }
-    else if (occ <= 2) launch(k_volpath<FeatAll, 2, true>);
-    else { if (sph) launch(k_volpath<FeatAll, 3, true>); else launch(k_volpath<FeatAll, 3, false>); }
+    // 0: no spheres; 2: a handful, tested after the traversal; 1: tested inside it (see DevTracer)
+    int sph = cfg.spheres == 0 ? 0 : (sc.n_spheres == 1 ? 2 : 1);   // (measured: one sphere — hetvol 184 -> 192 Msamples/s; two or three — volpath_test4 / 5 / 6 7 - 9 % slower than inside the traversal)
+    if (const char *e = getenv("LJ_TUNE_VOLPATH_SPHERES")) sph = cfg.spheres == 0 ? 0 : (atoi(e) == 1 ? 1 : sph);
+    auto pick = [&](auto ft, auto occ_c) {
+        using Ft = decltype(ft); constexpr int O = decltype(occ_c)::value;
+        if (sph == 0) launch(k_volpath<Ft, O, 0>); else if (sph == 2) launch(k_volpath<Ft, O, 2>); else launch(k_volpath<Ft, O, 1>);
+    };
+    if (v == 0) pick(FeatLambert{}, std::integral_constant<int, 3>{});
+    else if (v == 2) pick(FeatClassic{}, std::integral_constant<int, 3>{});
+    else if (occ <= 2) launch(k_volpath<FeatAll, 2, 1>);
+    else pick(FeatAll{}, std::integral_constant<int, 3>{});
 }
 int volpath_blocks_per_cu(const DScene &sc) {   // workgroups that stay resident per CU: the persistent grid is n_cus x this
     if (const char *e = getenv("LJ_TUNE_VOLPATH_BLOCKS_PER_CU")) return atoi(e) > 0 ? atoi(e) : 1;

@@ -89,7 +89,7 @@ ljd::DScene FlatScene::host_view() const {
     s.nodes = nodes.data(); s.n_nodes = (int)nodes.size();
     s.nodes8 = nodes8.data(); s.n_nodes8 = (int)nodes8.size(); s.node8_stride = (int32_t)sizeof(ljd::DNode8);
     s.leaf_prims = leaf_prims.data(); s.n_prims = (int)leaf_prims.size();
-    s.prims = prims.data(); s.spheres = spheres.data();
+    s.prims = prims.data(); s.spheres = spheres.data(); s.n_spheres = (int32_t)n_spheres;
     s.materials = materials.data(); s.n_materials = (int)materials.size();
     s.lights = lights.data(); s.n_lights = (int)lights.size();
     s.light_cdf = light_cdf.data(); s.light_tris = light_tris.data(); s.light_tri_cdf = light_tri_cdf.data();
@@ -216,7 +216,7 @@ FlatScene flatten_scene(const LjSceneDesc &d) {
         if (!medium_ok(sh.interior_medium_id) || !medium_ok(sh.exterior_medium_id)) throw LjError(LJ_ERR_INVALID_ARG, "shape references a missing medium");
         F.shape_media.push_back(sh.interior_medium_id); F.shape_media.push_back(sh.exterior_medium_id);
         if (sh.kind == LJ_SHAPE_SPHERE) {
-            ljd::DSphere ds; for (int k = 0; k < 3; k++) ds.center[k] = sh.position[k]; ds.radius = sh.radius;
+            ljd::DSphere ds{}; for (int k = 0; k < 3; k++) ds.center[k] = sh.position[k]; ds.radius = sh.radius; ds.gprim = (int32_t)F.prims.size();
             int slot = (int)F.spheres.size(); F.spheres.push_back(ds);
             ljd::DPrimShade ps{}; ps.shape_id = si; ps.prim_id = 0; ps.material_id = sh.material_id; ps.light_id = sh.area_light_id;
             ps.flags = 1; ps.sphere_slot = slot;
