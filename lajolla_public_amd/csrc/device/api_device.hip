@@ -134,7 +134,7 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
             const uint64_t np = std::min<uint64_t>(pix_per_pass, n_pix - p0);
             const uint64_t total = np * (uint64_t)plan.spp;
             ljd::DPass pass{};
-            pass.pixel_list = (const uint32_t *)ctx->pixel_list.p + p0; pass.n_pixels = (uint32_t)np; pass.spp = (uint32_t)plan.spp;
+            pass.pixel_list = (const uint32_t *)ctx->pixel_list.p + p0; pass.n_pixels = (uint32_t)np; ljd::set_pass_divisors(pass, (uint32_t)plan.spp, (uint32_t)sc->flat.cam.width);
             pass.seed = plan.seed; pass.sample_rgb = (float *)ctx->sample_rgb.p;
             // persistent grid (k_volpath regenerates paths): as many workgroups as stay resident, fewer for a small pass
             const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((total + 255) / 256, (uint64_t)ctx->n_cus * (uint64_t)ljd::volpath_blocks_per_cu(ds)));
@@ -187,7 +187,7 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
             const uint64_t np = std::min<uint64_t>(pix_per_pass, n_pix - p0);
             const uint64_t total = np * (uint64_t)plan.spp;
             ljd::DPass pass{};
-            pass.pixel_list = (const uint32_t *)ctx->pixel_list.p + p0; pass.n_pixels = (uint32_t)np; pass.spp = (uint32_t)plan.spp;
+            pass.pixel_list = (const uint32_t *)ctx->pixel_list.p + p0; pass.n_pixels = (uint32_t)np; ljd::set_pass_divisors(pass, (uint32_t)plan.spp, (uint32_t)sc->flat.cam.width);
             pass.seed = plan.seed; pass.sample_rgb = (float *)ctx->sample_rgb.p;
             HIP_CHECK(hipMemsetAsync(ctx->mega_state.p, 0, 64, stream));
             uint32_t grab = grab_max;
@@ -316,7 +316,7 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
         const uint64_t np = std::min<uint64_t>(pix_per_pass, n_pix - p0);
         const uint64_t total = np * (uint64_t)plan.spp;
         ljd::DPass pass{};
-        pass.pixel_list = (const uint32_t *)ctx->pixel_list.p + p0; pass.n_pixels = (uint32_t)np; pass.spp = (uint32_t)plan.spp;
+        pass.pixel_list = (const uint32_t *)ctx->pixel_list.p + p0; pass.n_pixels = (uint32_t)np; ljd::set_pass_divisors(pass, (uint32_t)plan.spp, (uint32_t)sc->flat.cam.width);
         pass.seed = plan.seed; pass.sample_rgb = (float *)ctx->sample_rgb.p;
         // contiguous sample ranges per workgroup, multiples of 64 so that a wave's first samples share a pixel
         {

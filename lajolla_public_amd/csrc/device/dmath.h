@@ -86,6 +86,15 @@ LJ_HD uint32_t pcg32_next(uint64_t &state, uint64_t inc) {
     uint32_t rot = (uint32_t)(old >> 59u);
     return (xorshifted >> rot) | (xorshifted << ((0u - rot) & 31u));
 }
+// n / d for a launch-constant d (DFastDiv, dtypes.h)
+LJ_HD uint32_t fast_div(uint32_t n, const DFastDiv &f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t t = __umulhi(f.m, n);
+#else
+    const uint32_t t = (uint32_t)(((uint64_t)f.m * n) >> 32);
+#endif
+    return (t + ((n - t) >> f.s1)) >> f.s2;
+}
 LJ_HD uint64_t pcg32_inc(uint64_t stream_id) { return (stream_id << 1u) | 1u; }
 LJ_HD uint64_t pcg32_init(uint64_t stream_id, uint64_t seed) {
     uint64_t inc = pcg32_inc(stream_id), state = 0;

@@ -829,9 +829,9 @@ struct ShadeCounters { uint32_t bounces, closest, shadow, done; };
 
 // Camera-sample generation: path_tracing.h:10-14 + render.cpp:82 (per-sample stream variant).
 LJ_HD void generate_path(const DScene &sc, const DPass &pass, uint32_t sample_id, PathState &ps) {
-    const uint32_t p = sample_id / pass.spp, s = sample_id - p * pass.spp;
+    const uint32_t p = fast_div(sample_id, pass.by_spp), s = sample_id - p * pass.spp;
     const uint32_t pixel = pass.pixel_list[p];
-    const int x = (int)(pixel % (uint32_t)sc.cam.width), y = (int)(pixel / (uint32_t)sc.cam.width);
+    const int y = (int)fast_div(pixel, pass.by_width), x = (int)(pixel - (uint32_t)y * (uint32_t)sc.cam.width);
     const uint64_t stream = (uint64_t)pixel * pass.spp + s;
     const uint64_t inc = pcg32_inc(stream);
     uint64_t st = pcg32_init(stream, pass.seed);
@@ -854,7 +854,8 @@ LJ_HD void generate_path(const DScene &sc, const DPass &pass, uint32_t sample_id
 // (ps.rad is the value of path_tracing() for this sample).
 template <class Ft = FeatAll>
 LJ_HD bool shade_path(const DScene &sc, const DPass &pass, PathState &ps, ShadeCounters &cnt) {
-    const uint64_t inc = pcg32_inc((uint64_t)pass.pixel_list[ps.sample / pass.spp] * pass.spp + (ps.sample % pass.spp));
+    const uint32_t pix_i = fast_div(ps.sample, pass.by_spp);
+    const uint64_t inc = pcg32_inc((uint64_t)pass.pixel_list[pix_i] * pass.spp + (ps.sample - pix_i * pass.spp));
     // pending next-event estimation of the previous vertex (path_tracing.h:207)
     if (ps.hcode & HIT_VIS_BIT) ps.rad = ps.rad + ps.nee;
     const bool primary = ps.p2 < 0.0f;

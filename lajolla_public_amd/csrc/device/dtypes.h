@@ -170,8 +170,9 @@ struct DScene {
     int32_t cam_medium, max_null_collisions;
     int32_t has_heterogeneous_medium;   // some medium is a grid volume (picks the k_volpath instantiation)
     int32_t vol_path_version;           // RenderOptions::vol_path_version (render.cpp:111-123): 1 and 2 are estimators of their own
-    // tiny scenes only (dscan.h): the flat leaf table; n_scan_leaves is a multiple of 4, 0 when the scene has none
-    const DScanLeaf *scan_leaves; int32_t n_scan_leaves;
+    // tiny scenes only (mega.hip): the flat leaf table; n_scan_leaves (0 when the scene has none) is a multiple of 4, the first n_scan_used
+    // entries are leaves, the rest padding that is never entered
+    const DScanLeaf *scan_leaves; int32_t n_scan_leaves, n_scan_used;
 };
 
 // ---- wavefront path queue: one slot per in-flight path, stored as eight arrays of 16-byte records so that every
@@ -207,11 +208,25 @@ struct DBlockState {
     unsigned long long bounce_iterations, rays_closest, rays_shadow, samples_done, path_steps;
 };
 
+// Division of a 32-bit number by a divisor that is fixed for a whole launch (samples per pixel, image width), as a multiplication
+// (Granlund & Montgomery 1994, fig. 4.1): q = (t + ((n - t) >> s1)) >> s2 with t = mulhi(m, n) — exact for every n < 2^32 and every
+// d >= 1; five instructions where the general division takes ~30.
+struct DFastDiv { uint32_t m, s1, s2, d; };
+inline DFastDiv make_fast_div(uint32_t d) {
+    DFastDiv f; uint32_t l = 0;
+    while (l < 32 && (1ull << l) < (unsigned long long)d) l++;   // l = ceil(log2 d)
+    f.m = (uint32_t)((((1ull << l) - d) << 32) / d) + 1u;
+    f.s1 = l < 1u ? l : 1u; f.s2 = l > 1u ? l - 1u : 0u; f.d = d;
+    return f;
+}
+
 struct DPass {
     const uint32_t *pixel_list;  // linear pixel index (y*w+x) of the p-th rendered pixel
     uint32_t n_pixels, spp;
+    DFastDiv by_spp, by_width;   // (set_pass_divisors)
     uint64_t seed;
     float *sample_rgb;           // 3 floats per sample of the pass: per-sample radiance (written once per sample)
 };
+inline void set_pass_divisors(DPass &p, uint32_t spp, uint32_t width) { p.spp = spp; p.by_spp = make_fast_div(spp); p.by_width = make_fast_div(width); }
 
 } // namespace ljd

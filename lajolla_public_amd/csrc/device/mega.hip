@@ -28,7 +28,7 @@ constexpr uint32_t kWaveScanBytes = 64 * 48 + 64 * 8 + 64 * 4 + kItemCap * 2;   
 
 struct ScanCtx {
     const LJ_CONST float *boxes;        // DScanLeaf records (8 dwords each), wave-uniform reads
-    int n_groups;                       // leaves / 4
+    int n_used;                         // leaves in the table
     const LJ_LDS int *leaf_tab;         // (first, count) per leaf
     const LJ_LDS v4f *lprims; int prim_stride;   // leaf-ordered primitives, transposed: v4f k of primitive i at [k * stride + i]
     const DSphere *spheres;
@@ -41,7 +41,7 @@ struct ScanCtx {
 
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
-// Leaf-box scan: bit k of a ray's mask = its segment [tnear, tfar] overlaps leaf box k.  Same slab arithmetic as the BVH node step
+// Leaf-box scan: one bit of a ray's mask per leaf box its segment [tnear, tfar] overlaps.  Same slab arithmetic as the BVH node step
 // (t = plane * (1/d) - o * (1/d), v_rcp reciprocals, exit widened by 4 ulp; the boxes carry the builder's 1e-5 padding), with
 // min / max instead of sign-selected planes because the planes are scalars here.  A direction component closer to zero than
 // 1e-18 is moved there: the slab then spans |t| < 1e18 * (distance to the plane) instead of producing inf - inf.  It can only
@@ -57,32 +57,59 @@ __device__ __forceinline__ ScanRay scan_ray(f3 org, f3 dir) {
     r.ox = org.x * r.ix; r.oy = org.y * r.iy; r.oz = org.z * r.iz;
     return r;
 }
-// one box against one ray; FAR: the segment has a far end (shadow rays; extension rays run to infinity)
+// One box against one ray; FAR: the segment has a far end (shadow rays; extension rays run to infinity).  Returns te - 1.0000005 tx in one
+// rounding: NEGATIVE (sign bit set) when the segment overlaps the box.  The scan shifts that sign bit into the ray's candidate mask with
+// one v_alignbit — no compare, no select.  (Against `te <= round(tx * 1.0000005)` the decision can differ only for |te - tx c| below one
+// rounding, i.e. for boxes the exact ray touches in a single point behind its own 4-ulp allowance; which boxes are entered never changes
+// a hit — the closest hit is the (t, primitive) minimum over every box that holds it — it only has to stay conservative.)
+// `tnear` must be a canonical number (the callers pass max(tnear, 0)), so that the maximum below compiles without a quieting copy.
 template <bool FAR>
-__device__ __forceinline__ bool scan_box(const LJ_CONST float *b, const ScanRay &r, float tnear, float tfar) {
+__device__ __forceinline__ float scan_box(const float (&b)[6], const ScanRay &r, float tnear, float tfar) {
     const float ax = __builtin_fmaf(b[0], r.ix, -r.ox), bx = __builtin_fmaf(b[3], r.ix, -r.ox);
     const float ay = __builtin_fmaf(b[1], r.iy, -r.oy), by = __builtin_fmaf(b[4], r.iy, -r.oy);
     const float az = __builtin_fmaf(b[2], r.iz, -r.oz), bz = __builtin_fmaf(b[5], r.iz, -r.oz);
     const float te = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tnear));
     float tx = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
     if (FAR) tx = fminf(tx, tfar);
-    return te <= tx * 1.0000005f;
+    return __builtin_fmaf(tx, -1.0000005f, te);
 }
-// Both rays of a path against every leaf box in ONE pass over the table: the boxes are fetched (scalar loads) and unpacked once, and the
-// two independent slab chains interleave.  `any_s` (wave-uniform): some lane has a shadow ray — else that half is skipped.
+__device__ __forceinline__ uint32_t shift_in_sign(uint32_t mask, float d) { return __builtin_amdgcn_alignbit(mask, f2u(d), 31u); }   // (mask << 1) | sign(d)
+
+// Both rays of a path (E: some lane has an extension ray, S: some lane has a shadow ray — wave-uniform, decided outside the loop) against
+// every leaf box in ONE pass over the table: the boxes are fetched (scalar loads, four boxes ahead) once, and the two independent slab
+// chains interleave.  Bit (n_used - 1 - k) of a ray's mask = its segment overlaps leaf box k (the bits are shifted in from below).
+template <bool E, bool S>
+__device__ __forceinline__ void scan_leaf_boxes(const ScanCtx &sx, const ScanRay &re, float tnear_e, const ScanRay &rs, float tnear_s, float tfar_s, uint32_t &me, uint32_t &ms) {
+    const int n = sx.n_used;
+    int k = 0;
+    for (; k + 4 <= n; k += 4) {
+        float b[4][6];
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int j = 0; j < 6; j++) b[c][j] = sx.boxes[(k + c) * 8 + j];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            if (E) me = shift_in_sign(me, scan_box<false>(b[c], re, tnear_e, INFINITY));
+            if (S) ms = shift_in_sign(ms, scan_box<true>(b[c], rs, tnear_s, tfar_s));
+        }
+    }
+    for (; k < n; k++) {
+        float b[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) b[j] = sx.boxes[k * 8 + j];
+        if (E) me = shift_in_sign(me, scan_box<false>(b, re, tnear_e, INFINITY));
+        if (S) ms = shift_in_sign(ms, scan_box<true>(b, rs, tnear_s, tfar_s));
+    }
+}
 __device__ __forceinline__ void scan_leaf_boxes2(const ScanCtx &sx, f3 org, f3 dir_e, float tnear_e, f3 dir_s, float tnear_s, float tfar_s, bool any_e, bool any_s,
                                                  uint32_t &me, uint32_t &ms) {
     const ScanRay re = scan_ray(org, dir_e), rs = scan_ray(org, dir_s);
+    tnear_e = fmaxf(tnear_e, 0.0f); tnear_s = fmaxf(tnear_s, 0.0f);
     me = 0u; ms = 0u;
-    for (int g = 0; g < sx.n_groups; g++) {
-        const LJ_CONST float *b = sx.boxes + g * 32;
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const uint32_t bit = 1u << (g * 4 + c);
-            if (any_e) me |= scan_box<false>(b + c * 8, re, tnear_e, INFINITY) ? bit : 0u;
-            if (any_s) ms |= scan_box<true>(b + c * 8, rs, tnear_s, tfar_s) ? bit : 0u;
-        }
-    }
+    if (any_e && any_s) scan_leaf_boxes<true, true>(sx, re, tnear_e, rs, tnear_s, tfar_s, me, ms);
+    else if (any_e) scan_leaf_boxes<true, false>(sx, re, tnear_e, rs, tnear_s, tfar_s, me, ms);
+    else if (any_s) scan_leaf_boxes<false, true>(sx, re, tnear_e, rs, tnear_s, tfar_s, me, ms);
 }
 
 // Closest hit of every lane's extension ray (has_e) and occlusion of its shadow ray (has_s), wave-synchronous: all 64 lanes
@@ -112,8 +139,8 @@ __device__ __forceinline__ void scan_trace(const ScanCtx &sx, bool has_e, bool h
             if (b == 0ull || n_items + 64u > kItemCap) break;
             if (has) {
                 uint32_t leaf, kind;
-                if (ms) { leaf = (uint32_t)__builtin_ctz(ms); ms &= ms - 1u; kind = 1u; }
-                else { leaf = (uint32_t)__builtin_ctz(me); me &= me - 1u; kind = 0u; }
+                if (ms) { leaf = (uint32_t)(sx.n_used - 1) - (uint32_t)__builtin_ctz(ms); ms &= ms - 1u; kind = 1u; }
+                else { leaf = (uint32_t)(sx.n_used - 1) - (uint32_t)__builtin_ctz(me); me &= me - 1u; kind = 0u; }
                 const uint32_t idx = n_items + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
                 sx.items[idx] = (uint16_t)(lane | (leaf << 6) | (kind << 11));
             }
@@ -207,7 +234,7 @@ __device__ __forceinline__ ScanCtx stage_scan(const DScene &sc, uint32_t at) {
     const v4f *src = reinterpret_cast<const v4f *>(sc.leaf_prims);
     for (int i = threadIdx.x; i < sc.n_prims * 3; i += kBlock) lp[(i % 3) * sc.n_prims + (i / 3)] = src[i];
     char *wave = base + lt_bytes + (uint32_t)sc.n_prims * 48u + (threadIdx.x >> 6) * kWaveScanBytes;
-    sx.boxes = (const LJ_CONST float *)(uintptr_t)sc.scan_leaves; sx.n_groups = sc.n_scan_leaves / 4;
+    sx.boxes = (const LJ_CONST float *)(uintptr_t)sc.scan_leaves; sx.n_used = sc.n_scan_used;
     sx.leaf_tab = lt; sx.lprims = lp; sx.prim_stride = sc.n_prims; sx.spheres = sc.spheres;
     sx.rays = (LJ_LDS v4f *)wave; sx.keys = (LJ_LDS unsigned long long *)(wave + 64 * 48); sx.occl = (LJ_LDS uint32_t *)(wave + 64 * 48 + 64 * 8);
     sx.items = (LJ_LDS uint16_t *)(wave + 64 * 48 + 64 * 8 + 64 * 4);

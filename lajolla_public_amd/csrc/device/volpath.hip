@@ -100,10 +100,10 @@ __device__ __forceinline__ void volpath_body(const DScene &sc, const DPass &pass
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(dead >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dead, 0u));
                 if (!live && rank < left) {
                     sample = w_next + rank;
-                    const uint32_t p = sample / pass.spp, k = sample - p * pass.spp;
+                    const uint32_t p = fast_div(sample, pass.by_spp), k = sample - p * pass.spp;
                     const uint32_t pixel = pass.pixel_list[p];
                     f3 rad;
-                    live = vol_path_begin<Ft>(sc, tr, (int)(pixel % (uint32_t)sc.cam.width), (int)(pixel / (uint32_t)sc.cam.width), (uint64_t)pixel * pass.spp + k, pass.seed, P, rad);
+                    live = vol_path_begin<Ft>(sc, tr, (int)(pixel - fast_div(pixel, pass.by_width) * (uint32_t)sc.cam.width), (int)fast_div(pixel, pass.by_width), (uint64_t)pixel * pass.spp + k, pass.seed, P, rad);
                     if (!live) finish(sample, rad, 0u);   // (the single-shot estimators of version 1 and 2)
                 }
                 w_next += n_dead < left ? n_dead : left;

@@ -104,7 +104,7 @@ ljd::DScene FlatScene::host_view() const {
     s.vol_path_version = vol_path_version;
     s.has_heterogeneous_medium = 0;
     for (const auto &m : media) if (m.kind == LJ_MEDIUM_HETEROGENEOUS) s.has_heterogeneous_medium = 1;
-    s.scan_leaves = scan_leaves.empty() ? nullptr : scan_leaves.data(); s.n_scan_leaves = (int32_t)scan_leaves.size();
+    s.scan_leaves = scan_leaves.empty() ? nullptr : scan_leaves.data(); s.n_scan_leaves = (int32_t)scan_leaves.size(); s.n_scan_used = scan_leaves.empty() ? 0 : n_scan_used;
     return s;
 }
 
@@ -307,6 +307,7 @@ FlatScene flatten_scene(const LjSceneDesc &d) {
             leaves.push_back(L);
         }
         if (leaves.size() <= 32 && F.leaf_prims.size() <= 256 && !leaves.empty()) {
+            F.n_scan_used = (int)leaves.size();
             while (leaves.size() % 4) { ljd::DScanLeaf L{}; for (int k = 0; k < 3; k++) L.lo[k] = L.hi[k] = 1e18f; L.first = 0; L.count = 0; leaves.push_back(L); }
             F.scan_leaves = leaves;
         }

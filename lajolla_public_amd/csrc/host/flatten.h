@@ -28,6 +28,7 @@ struct FlatScene {
     std::vector<ljd::DMedium> media;
     std::vector<float> volume_data;
     std::vector<int32_t> shape_media;
+    int n_scan_used = 0;                       // leaves among scan_leaves (the rest pads the table to a multiple of four)
     std::vector<ljd::DScanLeaf> scan_leaves;   // tiny scenes only (else empty): the flat leaf table of device/dscan.h
     int cam_medium = -1, max_null_collisions = 1000, vol_path_version = 0;
     int envmap_light_id = -1, max_depth = -1, rr_depth = 5, spp = 4, integrator = LJ_INTEGRATOR_PATH;

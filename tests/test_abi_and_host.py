@@ -151,6 +151,19 @@ def test_guided_cdf_search_is_the_full_search():
     assert tw.lib.twin_cdf_guide_mismatches(tw.h, C.c_int(20000)) == 0
 
 
+def test_division_by_launch_constants_is_exact():
+    """Camera-sample generation divides by the samples per pixel and the image width through a multiplication (dmath.h fast_div):
+    it must be the machine's quotient for every 32-bit numerator — small, odd, power-of-two and huge divisors alike."""
+    import ctypes as C
+    tw = Twin(lj.parse_scene(scene_path("cbox")))
+    divs = [1, 2, 3, 4, 5, 6, 7, 9, 10, 16, 31, 32, 33, 64, 100, 255, 256, 257, 512, 575, 683, 768, 1000, 1023, 1024, 1025, 4096, 65535, 65536, 65537,
+            (1 << 20) + 7, (1 << 24) - 1, (1 << 31) - 1, 1 << 31, (1 << 31) + 1, (1 << 32) - 2, (1 << 32) - 1]
+    divs += [int(x) for x in np.random.default_rng(7).integers(1, 1 << 32, 200)]
+    arr = (C.c_uint32 * len(divs))(*divs)
+    tw.lib.twin_fast_div_mismatches.restype = C.c_longlong
+    assert tw.lib.twin_fast_div_mismatches(arr, C.c_int(len(divs)), C.c_int(20000)) == 0
+
+
 def test_unsupported_variants_fail_loudly():
     """Anything the device path does not implement must raise LJ_ERR_UNSUPPORTED at upload, never fall back."""
     hs = lj.parse_scene(scene_path("cbox"))

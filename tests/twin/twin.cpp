@@ -126,7 +126,7 @@ void twin_render_samples(void *tv, int spp, int max_depth, int use_max_depth, ui
     const int w = sc.cam.width, cw = x1 - x0, ch = y1 - y0;
     std::vector<uint32_t> pixels;
     for (int y = y0; y < y1; y++) for (int x = x0; x < x1; x++) pixels.push_back((uint32_t)(y * w + x));
-    DPass pass{}; pass.pixel_list = pixels.data(); pass.n_pixels = (uint32_t)pixels.size(); pass.spp = (uint32_t)spp;
+    DPass pass{}; pass.pixel_list = pixels.data(); pass.n_pixels = (uint32_t)pixels.size(); set_pass_divisors(pass, (uint32_t)spp, (uint32_t)sc.cam.width);
     pass.seed = seed ? seed : 0x853c49e6748fea9bULL; pass.sample_rgb = out;
     const uint64_t total = (uint64_t)cw * ch * spp;
     if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
@@ -361,6 +361,25 @@ void twin_intersect_work(void *tv, int64_t n, const LjRay *rays, unsigned long l
     }
     work[0] += mem.n_nodes; work[1] += mem.n_prims;
 }
+// fast_div (dmath.h) against the machine's division: every divisor of `divs`, numerators at the ends of the range, around every multiple
+// of the divisor near them, and random ones.  Returns the number of disagreements.
+long long twin_fast_div_mismatches(const uint32_t *divs, int n_divs, int n_random) {
+    long long bad = 0;
+    uint64_t st = 0x9e3779b97f4a7c15ull;
+    for (int i = 0; i < n_divs; i++) {
+        const uint32_t d = divs[i];
+        const DFastDiv f = make_fast_div(d);
+        auto check = [&](uint32_t n) { if (fast_div(n, f) != n / d) bad++; };
+        for (uint32_t k = 0; k < 4; k++) { check(k); check(0xffffffffu - k); check(0x80000000u - k); check(0x80000000u + k); }
+        for (uint64_t q : {1ull, 2ull, 3ull, (0xffffffffull / d) / 2, 0xffffffffull / d - 1, 0xffffffffull / d}) {
+            const uint64_t m = q * d;
+            for (long long o = -2; o <= 2; o++) { const long long n = (long long)m + o; if (n >= 0 && n <= 0xffffffffll) check((uint32_t)n); }
+        }
+        for (int r = 0; r < n_random; r++) { st = st * 6364136223846793005ULL + 1442695040888963407ULL; check((uint32_t)(st >> 32)); check((uint32_t)(st >> 45)); }
+    }
+    return bad;
+}
+
 // sample_cdf_guided against the full bisection on every environment-map table of the scene: random u, and the values around every
 // bin edge (b / n and its float neighbours) where a guide that is one entry short would show.  Returns the number of disagreements.
 long long twin_cdf_guide_mismatches(void *tv, int n_random) {
