@@ -210,8 +210,8 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
             }
             st.mega_launches++; st.wavefront_steps++;
             if (rgb_dev) ljd::launch_resolve(pass, (uint32_t)np, rgb_dev, stream);
-            unsigned long long h[5];
-            HIP_CHECK(hipMemcpyAsync(h, (char *)ctx->mega_state.p + 8, sizeof(h), hipMemcpyDeviceToHost, stream));
+            unsigned long long *h = ctx->stats_host;
+            HIP_CHECK(hipMemcpyAsync(h, (char *)ctx->mega_state.p + 8, 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
             if (samples_host) HIP_CHECK(hipMemcpyAsync(samples_host + p0 * (uint64_t)plan.spp * 3, ctx->sample_rgb.p, total * 12, hipMemcpyDeviceToHost, stream));
             HIP_CHECK(hipStreamSynchronize(stream));
             if (h[3] != total)
@@ -457,6 +457,7 @@ int lj_context_create(int device_id, lj_context **out) {
         HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_caller, hipEventDisableTiming));
         ctx->blocks.alloc(sizeof(ljd::DBlockState) * kMaxBlocks);
         HIP_CHECK(hipHostMalloc((void **)&ctx->blocks_host, sizeof(ljd::DBlockState) * kMaxBlocks, hipHostMallocDefault));
+        HIP_CHECK(hipHostMalloc((void **)&ctx->stats_host, 64, hipHostMallocDefault));
         HIP_CHECK(hipEventCreate(&ctx->ev_begin)); HIP_CHECK(hipEventCreate(&ctx->ev_end));
         HIP_CHECK(hipEventCreate(&ctx->ev_k0)); HIP_CHECK(hipEventCreate(&ctx->ev_k1));
         *out = ctx.release();
@@ -473,6 +474,7 @@ void lj_context_destroy(lj_context *ctx) {
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->ev_caller) (void)hipEventDestroy(ctx->ev_caller);
     if (ctx->blocks_host) (void)hipHostFree(ctx->blocks_host);
+    if (ctx->stats_host) (void)hipHostFree(ctx->stats_host);
     for (hipEvent_t e : {ctx->ev_begin, ctx->ev_end, ctx->ev_k0, ctx->ev_k1}) if (e) (void)hipEventDestroy(e);
     delete ctx;
 }

@@ -76,6 +76,7 @@ struct lj_context {
     uint64_t pixel_list_key = 0;   // which pixel list `pixel_list` holds (RenderPlan::pixels_key), 0: none
     DevBuf mega_state;   // k_mega: [0] the grid-wide camera-sample counter (uint32), [8..] five 64-bit statistics
     ljd::DBlockState *blocks_host = nullptr;  // pinned, kMaxBlocks entries
+    unsigned long long *stats_host = nullptr; // pinned, 8 entries: where a launch's statistics are read back (one wait per pass, no staged copy)
     hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_k0 = nullptr, ev_k1 = nullptr;
 };
 

@@ -170,16 +170,20 @@ LJ_HD uint32_t node8_hits(const uint32_t *w, const Ray8 &r, float tnear, float t
     const float bx = __builtin_fmaf(px.f, r.ix, -r.oix), by = __builtin_fmaf(py.f, r.iy, -r.oiy), bz = __builtin_fmaf(pz.f, r.iz, -r.oiz);
     // dwords 8..19: qlo_x[0-3] qlo_x[4-7] qlo_y.. qlo_y.. | qlo_z qlo_z qhi_x qhi_x | qhi_y qhi_y qhi_z qhi_z
     const bool nx = (r.oct & 1u) != 0u, ny = (r.oct & 2u) != 0u, nz = (r.oct & 4u) != 0u;
+    // Slots 7 .. 0, each shifting the sign of (entry - 1.0000005 exit) into the mask from below (one fma and one v_alignbit per slot instead of
+    // multiply, compare, select, or): negative = the segment enters the box.  Against `entry <= round(exit * 1.0000005)` the decision can
+    // differ only within one rounding of the 4-ulp allowance — the test stays conservative, and which boxes are entered never changes a hit.
     uint32_t hits = 0u;
-    for (int h = 0; h < 2; h++) {
+    for (int h = 1; h >= 0; h--) {
         const uint32_t lox = w[8 + h], loy = w[10 + h], loz = w[12 + h], hix = w[14 + h], hiy = w[16 + h], hiz = w[18 + h];
         const uint32_t nearx = nx ? hix : lox, farx = nx ? lox : hix;
         const uint32_t neary = ny ? hiy : loy, fary = ny ? loy : hiy;
         const uint32_t nearz = nz ? hiz : loz, farz = nz ? loz : hiz;
-        for (int k = 0; k < 4; k++) {
+        for (int k = 3; k >= 0; k--) {
             const float t0 = fmaxf(fmaxf(__builtin_fmaf(byte_f(nearx, k), ax, bx), __builtin_fmaf(byte_f(neary, k), ay, by)), fmaxf(__builtin_fmaf(byte_f(nearz, k), az, bz), tnear));
             const float t1 = fminf(fminf(__builtin_fmaf(byte_f(farx, k), ax, bx), __builtin_fmaf(byte_f(fary, k), ay, by)), fminf(__builtin_fmaf(byte_f(farz, k), az, bz), tfar));
-            hits |= (t0 <= t1 * 1.0000005f) ? (1u << (4 * h + k)) : 0u;
+            union { float f; uint32_t u; } d; d.f = __builtin_fmaf(t1, -1.0000005f, t0);
+            hits = (hits << 1) | (d.u >> 31);
         }
     }
     return hits;

@@ -114,9 +114,20 @@ __device__ __forceinline__ void trav_finish(LaneTrav &L) {
     L.best.u = L.best.u * rS; L.best.v = L.best.v * rS;
 }
 
+#ifndef LJ_EXT_CSW_MINMAX
+#define LJ_EXT_CSW_MINMAX 0   // 1: the distances of a compare-exchange are taken as min / max (nothing waits on the comparison's mask)
+#endif
+#ifndef LJ_EXT_SORT
+#define LJ_EXT_SORT 5         // compare-exchanges of a node step: 5 = the four children fully ordered; 4 = nearest and farthest in place; 3 = nearest only
+#endif
 __device__ __forceinline__ void csw(float &ta, int &ca, float &tb, int &cb) {  // compare-exchange: nearer entry first
     const bool sw = tb < ta;
-    const float t0 = sw ? tb : ta, t1 = sw ? ta : tb; const int c0 = sw ? cb : ca, c1 = sw ? ca : cb;
+#if LJ_EXT_CSW_MINMAX
+    const float t0 = fminf(ta, tb), t1 = fmaxf(ta, tb);   // (entry distances are numbers: same values as the selects)
+#else
+    const float t0 = sw ? tb : ta, t1 = sw ? ta : tb;
+#endif
+    const int c0 = sw ? cb : ca, c1 = sw ? ca : cb;
     ta = t0; tb = t1; ca = c0; cb = c1;
 }
 
@@ -161,8 +172,13 @@ __device__ __forceinline__ void trav_node_step(const TreeView &tv, LaneTrav &L) 
     }
     // (an entry distance is finite for a hit: it is bounded by best.t or by the finite far planes)
     csw(t0[0], c[0], t0[1], c[1]); csw(t0[2], c[2], t0[3], c[3]);
-    csw(t0[0], c[0], t0[2], c[2]); csw(t0[1], c[1], t0[3], c[3]);
+    csw(t0[0], c[0], t0[2], c[2]);
+#if LJ_EXT_SORT >= 4
+    csw(t0[1], c[1], t0[3], c[3]);
+#endif
+#if LJ_EXT_SORT >= 5
     csw(t0[1], c[1], t0[2], c[2]);
+#endif
     if (fast) {
         const int sp0 = L.sp;
         tv.stack[L.sp * kBlock] = c[3]; L.sp += (t0[3] < inf) ? 1 : 0;   // misses sort last: a slot written for a miss is
