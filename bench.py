@@ -277,8 +277,10 @@ def main():
                 a = insts / (kd["ms"] * 1e-3) / 1e9
                 r.update({"achieved": round(a, 1), "peak": PEAK_GWINST, "unit": "G wave-instructions/s", "frac": round(a / PEAK_GWINST, 5),
                           "valu_active_lane_frac": prof.get("valu_active_lane_frac"), "valu_wave_insts_per_render": int(insts)})
-                if prof.get("floor_wave_insts"):   # instructions the algorithm needs at full lane use: distance to the floor, not utilisation
+                if prof.get("floor_wave_insts"):   # the issue floor: what the launch would take if every instruction it issues ran
+                    # with all 64 lanes live, at the chip's issue peak, over what it takes — distance to a floor, where `frac` is a utilisation
                     r["floor_frac"] = round(prof["floor_wave_insts"] * m["share"] / (kd["ms"] * 1e-3) / 1e9 / PEAK_GWINST, 5)
+                    r["floor_kind"] = prof.get("floor_kind")
             else:
                 r["note"] = "VALU-bound kernel without a current PMC profile to take its instruction count from: the figures are its algorithmic HBM rate"
         if prof and "fetch_bytes" in prof and "write_bytes" in prof:

@@ -42,13 +42,16 @@ for i, wl in enumerate(workloads):
             e["valu_issue_frac"] = round(e["SQ_INSTS_VALU"] / (e["ns_under_sq_pass"] * 1e-9) / PEAK_WAVE_INST_PER_S, 4)
             if e.get("SQ_THREAD_CYCLES_VALU"): e["valu_active_lane_frac"] = round(e["SQ_THREAD_CYCLES_VALU"] / e["SQ_INSTS_VALU"] / 64.0, 4)
             if e.get("SQ_WAVE_CYCLES") and e.get("SQ_WAIT_ANY"): e["wave_time_waiting_frac"] = round(e["SQ_WAIT_ANY"] / e["SQ_WAVE_CYCLES"], 4)
+            # the issue floor bench.py prices `floor_frac` against: the instructions the launch would issue if every one of
+            # them ran with all 64 lanes live — SQ_THREAD_CYCLES_VALU / 64 — at the chip's issue peak; a hand-derived count overrides it below
+            if e.get("SQ_THREAD_CYCLES_VALU"): e["floor_wave_insts"] = e["SQ_THREAD_CYCLES_VALU"] / 64.0; e["floor_kind"] = "lane-weighted executed instructions"
 # instruction floors derived by hand ride along when present
 floors = os.path.join(root, "profiles", f"{rnd}_floors.json")
 if os.path.exists(floors):
     for wl, ks in json.load(open(floors)).items():
         for k, v in ks.items():
             if wl in out["workloads"] and k in out["workloads"][wl]:
-                out["workloads"][wl][k]["floor_wave_insts"] = v
+                out["workloads"][wl][k]["floor_wave_insts"] = v; out["workloads"][wl][k]["floor_kind"] = "hand-derived (DESIGN.md section 4)"
 json.dump(out, open(os.path.join(root, f"gpurun_out/{rnd}_counters.json"), "w"), indent=1, sort_keys=True)
 keep = ("launches", "fetch_bytes", "write_bytes", "valu_issue_frac", "valu_active_lane_frac", "wave_time_waiting_frac")
 print(json.dumps({wl: {k: {x: e[x] for x in keep if x in e} for k, e in ks.items()} for wl, ks in out["workloads"].items()}, indent=1))
