@@ -248,7 +248,7 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
     // the Disney / all-features shade kernels (164 VGPRs, three waves per SIMD) leave an extend kernel no registers to run beside
     // them: lanes would only time-slice the GPU (disney_bsdf 256 spp: 104 ms with one lane, 116 with two; a 64-spp render, which fits
     // the pool at once, is the other way round by 7 %)
-    if (sc->scfg.variant >= 3) n_lanes = 1;   // (FeatDisney, FeatAll)
+    if (sc->scfg.variant >= 4) n_lanes = 1;   // (FeatDisney, FeatAll)
     // a tree beyond the LDS image (nodes fetched through L2): one lane.  Its extend launches fill every CU (five workgroups of 30 KiB
     // LDS and 92 VGPRs each), so the lanes' kernels queue up behind one another instead of running side by side (tools/lanes_sweep.sh,
     // sponza 256 spp: 202.5 ms with one lane, 208.8 with four)

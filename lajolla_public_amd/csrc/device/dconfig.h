@@ -6,7 +6,7 @@
 namespace ljd {
 
 // feature-set instantiations of the shading code (dshade.h lists them, smallest first)
-constexpr int kNumShadeVariants = 5;
+constexpr int kNumShadeVariants = 6;
 constexpr int kShadeVariantAll = kNumShadeVariants - 1;
 
 // LDS image of the extend kernel: stack levels, staged nodes / primitives, which instantiation

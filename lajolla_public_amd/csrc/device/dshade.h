@@ -24,17 +24,19 @@ using FeatAll = ShadeFeat<0x1ffu, true, true, true>;
 // The feature sets device code is compiled for, smallest first; variant v of a scene = the first one that
 // covers its Material / Texture / Light alternatives.  kinds: bit k = Material alternative k (material.h:102-110).
 using FeatLambert = ShadeFeat<0x001u, false, false, false>;      // constant-colour diffuse surfaces, mesh lights (cbox)
+using FeatPlastic = ShadeFeat<0x003u, false, false, true>;       // diffuse + roughplastic in constant colours, mesh and sphere lights (veach_mi)
 using FeatLambertTex = ShadeFeat<0x001u, true, false, true>;     // + image / checker textures, sphere lights (sponza)
 using FeatClassic = ShadeFeat<0x007u, true, true, true>;         // diffuse, roughplastic, roughdielectric + everything else
 using FeatDisney = ShadeFeat<0x101u, true, true, false>;         // diffuse + the Disney principled BSDF, textures, environment map (disney_bsdf.xml)
-// (kNumShadeVariants = 5 and kShadeVariantAll, the index of the one that covers everything, live in dconfig.h)
+// (kNumShadeVariants = 6 and kShadeVariantAll, the index of the one that covers everything, live in dconfig.h)
 // calls fn(Feat{}) for variant v
 template <class Fn> inline void with_shade_variant(int v, Fn &&fn) {
     switch (v) {
         case 0: fn(FeatLambert{}); break;
-        case 1: fn(FeatLambertTex{}); break;
-        case 2: fn(FeatClassic{}); break;
-        case 3: fn(FeatDisney{}); break;
+        case 1: fn(FeatPlastic{}); break;
+        case 2: fn(FeatLambertTex{}); break;
+        case 3: fn(FeatClassic{}); break;
+        case 4: fn(FeatDisney{}); break;
         default: fn(FeatAll{}); break;
     }
 }

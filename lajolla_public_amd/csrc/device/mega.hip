@@ -251,6 +251,10 @@ size_t scan_smem(int n_scan_leaves, int n_prims) { return (((size_t)n_scan_leave
 #endif
 template <class Ft> struct MegaOccupancy { static constexpr int waves = 3; };
 template <> struct MegaOccupancy<FeatLambert> { static constexpr int waves = LJ_MEGA_OCC; };
+#ifndef LJ_MEGA_OCC_PLASTIC
+#define LJ_MEGA_OCC_PLASTIC 4
+#endif
+template <> struct MegaOccupancy<FeatPlastic> { static constexpr int waves = LJ_MEGA_OCC_PLASTIC; };
 
 // stats: [0] bounce iterations, [1] closest-hit rays, [2] shadow rays, [3] samples finished, [4] path steps (shade_path calls)
 template <class Ft, bool SPHERES>
@@ -355,7 +359,11 @@ size_t mega_smem(const DScene &sc, const ShadeConfig &scfg) {
 }
 
 // workgroups per CU a mega launch keeps resident (the grid is persistent: n_cus * this)
-int mega_blocks_per_cu(const ShadeConfig &scfg) { return scfg.variant == 0 ? LJ_MEGA_OCC : 3; }
+int mega_blocks_per_cu(const ShadeConfig &scfg) {
+    int waves = 3;
+    with_shade_variant(scfg.variant, [&](auto ft) { waves = MegaOccupancy<decltype(ft)>::waves; });
+    return waves;
+}
 
 void launch_mega(const DScene &sc, const DPass &pass, const ShadeConfig &scfg, bool spheres, uint32_t n_samples, uint32_t grab, uint32_t *sample_counter,
                  unsigned long long *stats, int grid, hipStream_t s) {

@@ -147,7 +147,7 @@ void launch_volpath(const DScene &sc, const DPass &pass, uint32_t n_samples, uin
     if (const char *e = getenv("LJ_TUNE_VOLPATH_GRAB")) grab = (uint32_t)(atoi(e) < 64 ? 64 : atoi(e)) & ~63u;
     auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), cfg.smem, s, sc, pass, n_samples, grab, counters, cfg.stack, cfg.lds_nodes, cfg.lds_prims, spill); };
     // feature sets compiled for this kernel: diffuse only / the three classic materials / everything (the smallest that covers the scene's)
-    const int v = shade_variant <= 0 ? 0 : (shade_variant <= 2 ? 2 : kShadeVariantAll);
+    const int v = shade_variant <= 0 ? 0 : (shade_variant <= 3 ? 3 : kShadeVariantAll);
     // 0: no spheres; 2: a handful, tested after the traversal; 1: tested inside it (see DevTracer)
     int sph = cfg.spheres == 0 ? 0 : (sc.n_spheres == 1 ? 2 : 1);   // (measured: one sphere — hetvol 184 -> 192 Msamples/s; two or three — volpath_test4 / 5 / 6 7 - 9 % slower than inside the traversal)
     if (const char *e = getenv("LJ_TUNE_VOLPATH_SPHERES")) sph = cfg.spheres == 0 ? 0 : (atoi(e) == 1 ? 1 : sph);
@@ -156,7 +156,7 @@ void launch_volpath(const DScene &sc, const DPass &pass, uint32_t n_samples, uin
         if (sph == 0) launch(k_volpath<Ft, O, 0>); else if (sph == 2) launch(k_volpath<Ft, O, 2>); else launch(k_volpath<Ft, O, 1>);
     };
     if (v == 0) pick(FeatLambert{}, std::integral_constant<int, 3>{});
-    else if (v == 2) pick(FeatClassic{}, std::integral_constant<int, 3>{});
+    else if (v == 3) pick(FeatClassic{}, std::integral_constant<int, 3>{});
     else if (occ <= 2) launch(k_volpath<FeatAll, 2, 1>);
     else pick(FeatAll{}, std::integral_constant<int, 3>{});
 }
