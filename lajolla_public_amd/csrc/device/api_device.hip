@@ -140,6 +140,7 @@ void run_render(lj_scene *sc, const RenderPlan &plan, float *rgb_dev, float *sam
             const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((total + 255) / 256, (uint64_t)ctx->n_cus * (uint64_t)ljd::volpath_blocks_per_cu(ds)));
             HIP_CHECK(hipMemsetAsync((char *)ctx->chunk_counter.p + 8, 0, 4, stream));   // the launch's sample counter
             ljd::launch_volpath(ds, pass, (uint32_t)total, (uint32_t *)ctx->chunk_counter.p, sc->ecfg, sc->scfg.variant,
+                                /* plain: */ (sc->feat_kinds & ~7u) == 0u && !sc->feat_textured && !sc->feat_envmap && !sc->feat_sphere_lights,
                                 ensure_spill(ctx, sc->ecfg.spill_levels, (uint32_t)grid), grid, stream);
             HIP_CHECK(hipGetLastError());
             st.samples += total; st.wavefront_steps++;

@@ -26,7 +26,7 @@ void launch_resolve(const DPass &pass, uint32_t n_pixels, float *rgb, hipStream_
 size_t tail_smem(const ExtendConfig &ecfg, const ShadeConfig &scfg);
 void launch_tail(const DScene &sc, const DPass &pass, const DQueue &q, DBlockState *blocks, uint32_t n_blocks, uint32_t seg, const ExtendConfig &ecfg, const ShadeConfig &scfg, int *spill, hipStream_t s);
 void launch_aux(const DScene &sc, const uint32_t *pixel_list, uint32_t n_pixels, int integrator, float *rgb, const ExtendConfig &cfg, int *spill, int grid, hipStream_t s);
-void launch_volpath(const DScene &sc, const DPass &pass, uint32_t n_samples, uint32_t *counters, const ExtendConfig &cfg, int shade_variant, int *spill, int grid, hipStream_t s);
+void launch_volpath(const DScene &sc, const DPass &pass, uint32_t n_samples, uint32_t *counters, const ExtendConfig &cfg, int shade_variant, bool plain, int *spill, int grid, hipStream_t s);
 int volpath_blocks_per_cu(const DScene &sc);
 void launch_trace_rays(const DScene &sc, const void *rays, long long n, void *hits, unsigned char *occ, const ExtendConfig &cfg, int *spill, int grid, hipStream_t s);
 // mega.hip

@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(kBlock, OCC) k_volpath(DScene sc, DPass pass, 
 }
 
 // ---------------------------------------------------------------- launcher
-void launch_volpath(const DScene &sc, const DPass &pass, uint32_t n_samples, uint32_t *counters, const ExtendConfig &cfg, int shade_variant, int *spill, int grid, hipStream_t s) {
+void launch_volpath(const DScene &sc, const DPass &pass, uint32_t n_samples, uint32_t *counters, const ExtendConfig &cfg, int shade_variant, bool plain, int *spill, int grid, hipStream_t s) {
     if (!n_samples) return;
     // three waves per SIMD (168 VGPRs, 65 - 115 of them spilled) for every scene: with regeneration it beats the unconstrained two-wave build
     // on homogeneous and heterogeneous media alike (hetvol 155 vs 187 ms, vol_cbox_teapot 180 vs 235, profiles/r03_sweeps.txt); the two-wave
@@ -155,7 +155,11 @@ void launch_volpath(const DScene &sc, const DPass &pass, uint32_t n_samples, uin
         using Ft = decltype(ft); constexpr int O = decltype(occ_c)::value;
         if (sph == 0) launch(k_volpath<Ft, O, 0>); else if (sph == 2) launch(k_volpath<Ft, O, 2>); else launch(k_volpath<Ft, O, 1>);
     };
+    // `plain`: the classic materials in constant colours under mesh lights (vol_cbox_teapot: diffuse walls, a rough dielectric teapot) — without the
+    // texture, environment-map and sphere-light code the tracer spills fewer registers at three waves per SIMD
+    using FeatClassicPlain = ShadeFeat<0x007u, false, false, false>;
     if (v == 0) pick(FeatLambert{}, std::integral_constant<int, 3>{});
+    else if (v == 3 && plain) pick(FeatClassicPlain{}, std::integral_constant<int, 3>{});
     else if (v == 3) pick(FeatClassic{}, std::integral_constant<int, 3>{});
     else if (occ <= 2) launch(k_volpath<FeatAll, 2, 1>);
     else pick(FeatAll{}, std::integral_constant<int, 3>{});
