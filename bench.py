@@ -48,6 +48,8 @@ def kernel_source_sha():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "lajolla_public_amd", "csrc", "device")
     for f in sorted(os.listdir(d)):
+        if not os.path.isfile(os.path.join(d, f)) or f.startswith("."):   # (sources only: no editor / test-runner droppings)
+            continue
         h.update(f.encode())
         h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]

@@ -10,6 +10,8 @@ root = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path
 h = hashlib.sha256()
 d = os.path.join(root, "lajolla_public_amd", "csrc", "device")
 for f in sorted(os.listdir(d)):
+    if not os.path.isfile(os.path.join(d, f)) or f.startswith("."):
+        continue
     h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
 out = {"kernel_source_sha": h.hexdigest()[:16],
        "source": "rocprofv3 --pmc <set> --kernel-trace, one run per set and workload (SQ set a for every bench workload; FETCH_SIZE | WRITE_SIZE | SQ set b for the headline "

@@ -21,10 +21,10 @@ for w, name in ((0, "BVH4 kernel k_extend (default for this scene)"), (1, "BVH8 
     tot = {}
     for tag in "ab":
         f = glob.glob(f"gpurun_out/spz_{tag}_{w}/*/*counter_collection.csv")[0]
-        d = pd.read_csv(f); d["k"] = d["Kernel_Name"].str.extract(r"(k_\w+)")
+        d = pd.read_csv(f); d["k"] = d["Kernel_Name"].str.extract(r"(k_\w+)")[0].fillna("")
         g = d[d["k"].str.startswith("k_extend")].groupby("Counter_Name")["Counter_Value"].sum()
         for c, v in g.items(): tot[c] = v
-    t = pd.read_csv(glob.glob(f"gpurun_out/spz_a_{w}/*/*kernel_trace.csv")[0]); t["k"] = t["Kernel_Name"].str.extract(r"(k_\w+)")
+    t = pd.read_csv(glob.glob(f"gpurun_out/spz_a_{w}/*/*kernel_trace.csv")[0]); t["k"] = t["Kernel_Name"].str.extract(r"(k_\w+)")[0].fillna("")
     ms = (t[t["k"].str.startswith("k_extend")].eval("End_Timestamp - Start_Timestamp").sum()) / 1e6
     print(f"extend launches, under the SQ pass: {ms:.2f} ms; rays {rays:.0f}")
     for c in sorted(tot): print(f"  {c:34s} {tot[c]:16.0f}   per ray {tot[c] / rays:10.3f}")
